@@ -1,0 +1,212 @@
+/* rt_abi.h -- C-ABI of librt_mi355x.so, the MI355X (gfx950) replacement for the per-ray hot path of
+ * gluyas/raytracer.
+ *
+ * What it replaces (all citations are file:line in the reference tree):
+ *   - the GPU shaders  src/raytracing.hlsl:60-349, src/random.hlsl:6-88, src/bluenoise.hlsl:44-245
+ *   - the DXR driver work those shaders call (TraceRay raytracing.hlsl:108-112, the BLAS/TLAS builds
+ *     raytracing.cpp:411-436,523-548, the 1-D texture fetch raytracing.hlsl:275)
+ *   - behind the host interface of src/raytracing.h:52-87 and src/bluenoise.h:69-88.
+ *
+ * Conventions (readme.md:15-17): row-major 4x4 matrices, row vectors premultiplied (v' = v * M, translation in
+ * row 3), right-handed, world Z-up, camera looks down -Z.
+ *
+ * Every entry point returns an int status (RT_OK == 0) instead of the reference's abort() (prelude.h:185).
+ * All work is ordered on one HIP stream per context; calls are asynchronous unless stated ("blocks").
+ * The context is not thread-safe (the reference keeps this state in namespace globals, raytracing.cpp:11-71).
+ * Plain pointers and sizes only: no torch / HIP types appear in any signature.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------------------- */
+enum {
+    RT_OK              = 0,
+    RT_ERR_INVALID     = 1, /* bad argument (null pointer, bad handle, bad size)                          */
+    RT_ERR_DEVICE      = 2, /* a HIP call failed; rt_last_error() has the text                            */
+    RT_ERR_STATE       = 3, /* call made in the wrong order (e.g. dispatch before build_tlas)             */
+    RT_ERR_LIMIT       = 4, /* a reference limit was exceeded (e.g. > 65535 vertices, raytracing.cpp:367) */
+    RT_ERR_UNSUPPORTED = 5
+};
+
+/* ---- parameter structs: same layout as the reference (prelude.h:96-148) -------------------------------- */
+#pragma pack(push, 4)
+
+typedef struct RtVertex {          /* prelude.h:96-99, 24 B */
+    float position[3];
+    float normal[3];
+} RtVertex;
+
+typedef uint16_t RtIndex;          /* prelude.h:66 */
+
+typedef struct RtSamplePoint {     /* prelude.h:101-104, 24 B */
+    float position[3];
+    float payload[3];              /* incident flux */
+} RtSamplePoint;
+
+typedef struct RtGlobals {         /* RaytracingGlobals, prelude.h:110-139, 156 B */
+    uint32_t frame_rng;                      /*   0 */
+    uint32_t accumulator_count;              /*   4 */
+    uint32_t samples_per_pixel;              /*   8 */
+    uint32_t bounces_per_sample;             /*  12 */
+    float    camera_to_world[16];            /*  16  row-major, row 3 = camera position */
+    float    camera_aspect;                  /*  80 */
+    float    camera_focal_length;            /*  84 */
+    uint32_t translucent_accumulator_count;  /*  88 */
+    uint32_t translucent_instance_stride;    /*  92  (written by rt_build_tlas, raytracing.cpp:461,491) */
+    int32_t  translucent_emission_bounces;   /*  96 */
+    float    translucent_refractive_index;   /* 100 */
+    float    translucent_bssrdf_scale;       /* 104  0 => dipole, else tabulated (raytracing.hlsl:327) */
+    float    translucent_bssrdf_fudge;       /* 108 */
+    float    translucent_scattering[3];      /* 112 */
+    uint32_t _pad124;
+    float    translucent_absorption[3];      /* 128 */
+    uint32_t _pad140;
+    float    light_color[3];                 /* 144 */
+} RtGlobals;
+
+typedef struct RtLocals {          /* RaytracingLocals, prelude.h:141-144 */
+    float   color[3];
+    int32_t translucent_id;
+} RtLocals;
+
+#pragma pack(pop)
+
+/* Shader enum, raytracing.h:19-25 */
+enum { RT_SHADER_LAMBERT = 0, RT_SHADER_LIGHT = 1, RT_SHADER_TRANSLUCENT = 2, RT_SHADER_COUNT = 3 };
+
+/* GeometryInstance + Material, raytracing.h:27-36.  Arrays are borrowed for the duration of rt_build_blas only
+ * (the reference frees them right after the call, main.cpp:344-346). */
+typedef struct RtGeometry {
+    const RtVertex* vertices;
+    size_t          vertex_count;
+    const RtIndex*  indices;       /* triangle list, indices local to `vertices` */
+    size_t          index_count;
+    int32_t         shader;        /* RT_SHADER_* */
+    float           color[3];
+} RtGeometry;
+
+typedef int32_t rt_blas;           /* handle returned by rt_build_blas (Blas, raytracing.h:38-45) */
+
+/* BlasInstance, raytracing.h:47-50 */
+typedef struct RtInstance {
+    float   transform[16];         /* object->world, row-major, row vectors */
+    rt_blas blas;
+} RtInstance;
+
+/* Parity tap: one record per (path, bounce) of the first sample of the last camera dispatch. */
+typedef struct RtHit {
+    int32_t  instance;             /* index into the rt_build_tlas array, -1 = miss                         */
+    int32_t  geometry;             /* GeometryIndex() within the BLAS                                       */
+    int32_t  primitive;            /* PrimitiveIndex() within the geometry                                  */
+    float    t;                    /* RayTCurrent(); +inf on a miss                                         */
+    float    u, v;                 /* attr.barycentrics (weights of vertex 1 and 2)                         */
+    uint32_t rng_after;            /* payload.rng after the hit shader ran                                  */
+    uint32_t valid;                /* 0 = the path was not alive at this bounce                             */
+} RtHit;
+
+typedef struct RtStats {
+    uint64_t rays_camera;          /* TraceRay-equivalents issued by camera dispatches since rt_reset_stats */
+    uint64_t rays_probe;           /* ... by translucent_rgen dispatches                                    */
+    uint64_t gather_pairs;         /* (hit, sample point) pairs evaluated by translucent_chit               */
+    uint64_t nodes_visited;        /* only counted while rt_set_flags(..., RT_FLAG_COUNT_TRAVERSAL) is set  */
+    uint64_t tris_tested;
+    uint64_t instances_entered;
+    uint64_t traverse_launches;
+    double   traverse_ms;          /* HIP-event time of the traverse kernels (only with RT_FLAG_TIME_KERNELS) */
+    double   blas_build_ms;        /* HIP-event time of the last rt_build_blas                              */
+    double   tlas_build_ms;
+    uint64_t blas_triangles;       /* triangles in all BLASes                                               */
+    uint64_t tlas_instances;
+} RtStats;
+
+/* rt_set_flags bits */
+enum {
+    RT_FLAG_COLLECT_SAMPLES   = 1 << 0, /* g_enable_translucent_sample_collection (raytracing.cpp:70)       */
+    RT_FLAG_ENABLE_SSS        = 1 << 1, /* g_enable_subsurface_scattering          (raytracing.cpp:71)      */
+    RT_FLAG_DOUBLE_DISPATCH   = 1 << 2, /* mimic the reference frame: camera_rgen twice (raytracing.cpp:688-741) */
+    RT_FLAG_CAPTURE_HITS      = 1 << 3, /* record RtHit for every bounce of sample 0 (parity tap)            */
+    RT_FLAG_COUNT_TRAVERSAL   = 1 << 4, /* count nodes/triangles/instances visited (slower kernel variant)   */
+    RT_FLAG_TIME_KERNELS      = 1 << 5, /* bracket every traverse launch with HIP events                     */
+    RT_FLAG_ALL_PHASE_GROUPS  = 1 << 6  /* blue-noise: run all 27 phase groups, not the reference's 24       */
+};
+
+typedef struct rt_ctx rt_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+/* Replaces Device::init + Raytracing::init + Bluenoise::init (device.cpp:17, raytracing.cpp:73, bluenoise.cpp:25).
+ * One process drives one GPU: n must be 1. */
+int  rt_create(const int* devices, int n, rt_ctx** out);
+void rt_destroy(rt_ctx* ctx);
+const char* rt_last_error(void);
+int  rt_abi_version(void);
+
+/* Run on a caller-owned HIP stream (hipStream_t passed as void*); NULL = the context's own stream. */
+int  rt_set_stream(rt_ctx* ctx, void* hip_stream);
+
+/* ---- Raytracing:: interface (raytracing.h:66-85) ------------------------------------------------------- */
+/* Raytracing::update_resolution (raytracing.cpp:143-187): (re)allocates the RGBA8 target and RGBA32F accumulator. */
+int  rt_update_resolution(rt_ctx* ctx, uint32_t width, uint32_t height);
+
+/* Raytracing::build_blas (raytracing.cpp:316-444): concatenates the geometries, rebases the 16-bit indices,
+ * creates one shader record per geometry and builds the bottom-level BVH on the GPU.  Blocks until the
+ * host arrays have been copied. */
+int  rt_build_blas(rt_ctx* ctx, const RtGeometry* geometries, int n, rt_blas* out);
+
+/* Raytracing::build_tlas (raytracing.cpp:446-551): resets all translucent instances, assigns InstanceID per
+ * BLAS in array order, sets translucent_instance_stride, builds the top-level BVH on the GPU. */
+int  rt_build_tlas(rt_ctx* ctx, const RtInstance* instances, int n);
+
+/* Raytracing::generate_translucent_samples (raytracing.cpp:553-650) + Bluenoise::generate_sample_points
+ * (bluenoise.cpp:95-358).  `rng_seed` replaces rand() at bluenoise.cpp:112 (instance i uses rng_seed + i),
+ * `phase_seed` replaces the rand() shuffle at bluenoise.cpp:308.  Blocks.  *total = total sample points. */
+int  rt_generate_translucent_samples(rt_ctx* ctx, float radius, uint32_t rng_seed, uint32_t phase_seed,
+                                     uint32_t* total);
+
+/* Raytracing::g_globals (raytracing.h:61).  translucent_instance_stride in *g is ignored (owned by build_tlas). */
+int  rt_set_globals(rt_ctx* ctx, const RtGlobals* g);
+int  rt_get_globals(rt_ctx* ctx, RtGlobals* g);
+int  rt_set_flags(rt_ctx* ctx, uint32_t flags);
+/* The g_bssrdf 1-D texture (raytracing.cpp:111-140): n radial samples per channel (r = data_l, g = data_m,
+ * b = data_s), zero-padded by the library to a multiple of 256 texels (2000 -> 2048).  profile 0 = data/skin_0.h
+ * (the one the reference includes, raytracing.cpp:112), profile 1 = data/skin_1.h.  Blocks. */
+int  rt_load_bssrdf_table(rt_ctx* ctx, int profile, const float* r, const float* g, const float* b, uint32_t n);
+int  rt_set_bssrdf_profile(rt_ctx* ctx, int profile);
+
+/* Raytracing::dispatch_rays (raytracing.cpp:652-747): [translucent_rgen] -> copy -> camera_rgen, then
+ * accumulator_count += 1 and translucent_accumulator_count += collect (raytracing.cpp:744-745). */
+int  rt_dispatch_rays(rt_ctx* ctx);
+
+/* ---- synchronisation and read-back -------------------------------------------------------------------- */
+int  rt_sync(rt_ctx* ctx);
+int  rt_read_accumulator(rt_ctx* ctx, float* rgba);           /* g_sample_accumulator, W*H*4 floats; blocks */
+int  rt_read_render_target(rt_ctx* ctx, uint8_t* rgba8);      /* g_render_target, W*H*4 bytes; blocks       */
+int  rt_read_hit_records(rt_ctx* ctx, uint32_t bounce, RtHit* out /* W*H */);
+/* translucent instance i (order of creation in rt_build_tlas): points (read buffer) and normals */
+int  rt_translucent_instance_count(rt_ctx* ctx, uint32_t* n);
+int  rt_sample_point_count(rt_ctx* ctx, uint32_t instance, uint32_t* n);
+int  rt_read_sample_points(rt_ctx* ctx, uint32_t instance, RtSamplePoint* points, float* normals /* 3 per point */);
+int  rt_get_stats(rt_ctx* ctx, RtStats* out);
+int  rt_reset_stats(rt_ctx* ctx);
+
+/* ---- multi-GPU helpers (no counterpart in the reference, which is single-GPU) ------------ */
+/* Tile split: this context renders only 32x32 tiles t with t % world == rank; other pixels are left untouched
+ * (zero after a reset) so that a sum over ranks reproduces the single-GPU image bit for bit. */
+int  rt_set_tile_split(rt_ctx* ctx, uint32_t rank, uint32_t world);
+/* Device pointers for collectives run by the caller (RCCL through torch.distributed): */
+int  rt_accumulator_device_ptr(rt_ctx* ctx, void** dev_ptr, size_t* bytes);
+/* Re-run the resolve step (raytracing.hlsl:161) after the caller has summed accumulators across ranks. */
+int  rt_resolve_render_target(rt_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

@@ -1,0 +1,231 @@
+// rt_dev_math.h -- per-ray arithmetic of the MI355X path tracer (device functions).
+//
+// Everything that decides where a ray goes (RNG, samplers, normals, the ray/triangle test) is written with
+// separate IEEE multiplies and adds (the library is compiled with -ffp-contract=off) so that closest-hit ids
+// are reproducible bit for bit; see DESIGN.md "Arithmetic contract" S1..S9.  Citations are file:line in the
+// reference tree (gluyas/raytracer).
+//
+// The functions are RT_DEV so that the same header also compiles as plain C++ for the CPU emulation tests
+// (tests/emu); the product only ever runs them on the GPU.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define RT_DEV __device__ __forceinline__
+#else
+#define RT_DEV inline
+#endif
+
+namespace rtd {
+
+typedef uint32_t u32;
+
+struct f3 { float x, y, z; };
+
+RT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+RT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+RT_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // S3
+RT_DEV f3 normalize3(f3 a) { float r = 1.0f / sqrtf(dot3(a, a)); return a * r; }      // S2
+RT_DEV bool any3(f3 a) { return a.x != 0.0f || a.y != 0.0f || a.z != 0.0f; }
+RT_DEV float comp3(f3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
+RT_DEV float as_f32(u32 u) { return __builtin_bit_cast(float, u); }
+RT_DEV u32 as_u32(float f) { return __builtin_bit_cast(u32, f); }
+RT_DEV float inf_f32() { return as_f32(0x7f800000u); }
+
+// ---- random.hlsl ------------------------------------------------------------------------------------------
+RT_DEV u32 wang_hash(u32 seed) {                      // random.hlsl:6-15
+    seed = (seed ^ 61u) ^ (seed >> 16);
+    seed *= 9u;
+    seed = seed ^ (seed >> 4);
+    seed *= 0x27d4eb2du;
+    seed = seed ^ (seed >> 15);
+    return seed;
+}
+RT_DEV u32 hash_u2(u32 x, u32 y) { return wang_hash(y) + 31u * wang_hash(x); }                   // random.hlsl:17-19
+RT_DEV u32 hash_u3(u32 x, u32 y, u32 z) { return wang_hash(z) + 31u * hash_u2(x, y); }            // random.hlsl:21-23
+RT_DEV u32 xorshift32(u32& s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }              // random.hlsl:30-36
+RT_DEV float random01(u32& s) { return as_f32(0x3f800000u | (0x007fffffu & xorshift32(s))) - 1.0f; } // :39-41
+RT_DEV float random11(u32& s) {                                                                  // :44-48
+    u32 r = xorshift32(s);
+    float r01 = as_f32(0x3f800000u | (0x007fffffu & r)) - 1.0f;
+    return as_f32(as_u32(r01) | (r & 0x80000000u));
+}
+
+// S1: sin and cos of phi in [0, 2 pi]
+RT_DEV void sincos_2pi(float phi, float& s_out, float& c_out) {
+    int   k  = (int) (phi * 0.636619772f + 0.5f);
+    float fk = (float) k;
+    float r  = phi - fk * 1.5703125f;
+    r = r - fk * 4.837512969970703125e-4f;
+    r = r - fk * 7.54978995489188e-8f;
+    float z = r * r;
+    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
+             - 0.5f * z + 1.0f;
+    int q = k & 3;
+    float s = (q & 1) ? pc : ps;
+    float c = (q & 1) ? ps : pc;
+    s_out = (q & 2) ? -s : s;
+    c_out = (q == 1 || q == 2) ? -c : c;
+}
+
+#define RT_TAU_F 6.28318530717958647692528676655900577f
+
+RT_DEV f3 random_on_sphere(u32& seed) {               // random.hlsl:70-75
+    float phi       = random01(seed) * RT_TAU_F;
+    float cos_theta = random11(seed);
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float s, c;
+    sincos_2pi(phi, s, c);
+    return mk3(sin_theta * c, sin_theta * s, cos_theta);
+}
+RT_DEV f3 random_on_hemisphere(u32& seed, f3 normal) { // random.hlsl:85-88
+    f3 unit = random_on_sphere(seed);
+    float d = 2.0f * dot3(normal, unit);
+    float m = d < 0.0f ? d : 0.0f;
+    return unit - m * normal;
+}
+
+RT_DEV float sign_f32(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+RT_DEV float schlick(float refractive_index, float cosine) { // raytracing.hlsl:211-222
+    float r0 = (refractive_index - 1.0f) / (refractive_index + 1.0f);
+    r0 *= r0;
+    float fresnel = 1.0f - cosine;
+    fresnel *= fresnel * fresnel * fresnel * fresnel;
+    fresnel *= 1.0f - r0;
+    fresnel += r0;
+    return fresnel;
+}
+
+// ---- transforms (row vectors) -------------------------------------------------------------------------------
+// 4x3 stored as 12 floats: rows 0..2 = linear part, row 3 = translation
+RT_DEV f3 xform_point43(const float* m, f3 p) {
+    return mk3(p.x * m[0] + p.y * m[3] + p.z * m[6] + m[9],
+               p.x * m[1] + p.y * m[4] + p.z * m[7] + m[10],
+               p.x * m[2] + p.y * m[5] + p.z * m[8] + m[11]);
+}
+RT_DEV f3 xform_dir43(const float* m, f3 p) {
+    return mk3(p.x * m[0] + p.y * m[3] + p.z * m[6],
+               p.x * m[1] + p.y * m[4] + p.z * m[7],
+               p.x * m[2] + p.y * m[5] + p.z * m[8]);
+}
+RT_DEV f3 xform_dir44(const float* m, f3 p) {          // mul(float4(p, 0), M).xyz
+    return mk3(p.x * m[0] + p.y * m[4] + p.z * m[8],
+               p.x * m[1] + p.y * m[5] + p.z * m[9],
+               p.x * m[2] + p.y * m[6] + p.z * m[10]);
+}
+RT_DEV f3 xform_point44(const float* m, f3 p) {        // mul(float4(p, 1), M).xyz
+    return mk3(p.x * m[0] + p.y * m[4] + p.z * m[8] + m[12],
+               p.x * m[1] + p.y * m[5] + p.z * m[9] + m[13],
+               p.x * m[2] + p.y * m[6] + p.z * m[10] + m[14]);
+}
+
+// ---- S4: watertight ray/triangle test, back faces culled -----------------------------------------------------
+struct RayPrep {
+    f3 o;
+    int kx, ky, kz;
+    float sx, sy, sz;
+};
+
+RT_DEV RayPrep prepare_ray(f3 o, f3 d) {
+    RayPrep r;
+    r.o = o;
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int kz = 0; float am = ax;
+    if (ay > am) { kz = 1; am = ay; }
+    if (az > am) { kz = 2; }
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    float dz = comp3(d, kz);
+    if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
+    r.kx = kx; r.ky = ky; r.kz = kz;
+    r.sx = comp3(d, kx) / dz;
+    r.sy = comp3(d, ky) / dz;
+    r.sz = 1.0f / dz;
+    return r;
+}
+
+RT_DEV bool intersect_triangle(const RayPrep& r, f3 p0, f3 p1, f3 p2, float& t_out, float& u_out, float& v_out) {
+    f3 A = p0 - r.o, B = p1 - r.o, C = p2 - r.o;
+    float Akz = comp3(A, r.kz), Bkz = comp3(B, r.kz), Ckz = comp3(C, r.kz);
+    float Ax = comp3(A, r.kx) - r.sx * Akz, Ay = comp3(A, r.ky) - r.sy * Akz;
+    float Bx = comp3(B, r.kx) - r.sx * Bkz, By = comp3(B, r.ky) - r.sy * Bkz;
+    float Cx = comp3(C, r.kx) - r.sx * Ckz, Cy = comp3(C, r.ky) - r.sy * Ckz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        double CxBy = (double) Cx * (double) By, CyBx = (double) Cy * (double) Bx;
+        U = (float) (CxBy - CyBx);
+        double AxCy = (double) Ax * (double) Cy, AyCx = (double) Ay * (double) Cx;
+        V = (float) (AxCy - AyCx);
+        double BxAy = (double) Bx * (double) Ay, ByAx = (double) By * (double) Ax;
+        W = (float) (BxAy - ByAx);
+    }
+    if (U < 0.0f || V < 0.0f || W < 0.0f) return false;
+    float det = U + V + W;
+    if (det == 0.0f) return false;
+    float Az = r.sz * Akz, Bz = r.sz * Bkz, Cz = r.sz * Ckz;
+    float T = U * Az + V * Bz + W * Cz;
+    t_out = T / det;
+    u_out = V / det;
+    v_out = W / det;
+    return true;
+}
+
+// ---- BSSRDF ---------------------------------------------------------------------------------------------------
+// S8: linear filtering of the zero-bordered 1-D table at texel coordinate u*N - 0.5 (raytracing.hlsl:275)
+RT_DEV f3 sample_bssrdf_table(const float* tab /* rgb interleaved */, int n, float u) {
+    float x = u * (float) n - 0.5f;
+    float fl = floorf(x);
+    float f = x - fl;
+    if (!(fl >= -1.0f && fl < (float) n)) return mk3(0.0f, 0.0f, 0.0f);
+    int i0 = (int) fl, i1 = i0 + 1;
+    f3 a = mk3(0.0f, 0.0f, 0.0f), b = a;
+    if (i0 >= 0 && i0 < n) a = mk3(tab[3 * i0], tab[3 * i0 + 1], tab[3 * i0 + 2]);
+    if (i1 >= 0 && i1 < n) b = mk3(tab[3 * i1], tab[3 * i1 + 1], tab[3 * i1 + 2]);
+    return a + f * (b - a);
+}
+
+// raytracing.hlsl:278-301, one channel.  The radius-independent terms are hoisted by the caller (DipoleConst).
+struct DipoleConst {
+    float z_real, z_virtual, sigma_tr, scale; // scale = albedo / (2 tau)
+};
+RT_DEV DipoleConst dipole_constants(float sigma_s, float sigma_a, float eta) {
+    DipoleConst c;
+    float attenuation = sigma_s + sigma_a;
+    float mean_free_path = 1.0f / attenuation;
+    float albedo = sigma_s / attenuation;
+    c.sigma_tr = sqrtf(3.0f * sigma_s * sigma_a);
+    float diffuse_fresnel = -1.440f / (eta * eta) + 0.710f / eta + 0.668f + 0.0636f * eta;
+    c.z_real = mean_free_path;
+    c.z_virtual = mean_free_path * (1.0f + 1.25f * (1.0f + diffuse_fresnel) / (1.0f - diffuse_fresnel));
+    c.scale = albedo / (2.0f * RT_TAU_F);
+    return c;
+}
+RT_DEV float dipole_eval(const DipoleConst& c, float radius) {
+    float d_real = radius + c.z_real;
+    float c_real = c.z_real * (c.sigma_tr + 1.0f / d_real);
+    float d_virtual = radius + c.z_virtual;
+    float c_virtual = c.z_virtual * (c.sigma_tr + 1.0f / d_virtual);
+    float m_real = c_real * expf(-c.sigma_tr * d_real) / (d_real * d_real);
+    float m_virtual = c_virtual * expf(-c.sigma_tr * d_virtual) / (d_virtual * d_virtual);
+    float r = c.scale * (m_real + m_virtual);
+    return r > 0.0f ? r : 0.0f;
+}
+
+RT_DEV unsigned char to_unorm8(float x) {             // S9
+    if (!(x > 0.0f)) return 0;
+    if (x > 1.0f) x = 1.0f;
+    return (unsigned char) (int) (x * 255.0f + 0.5f);
+}
+
+} // namespace rtd

@@ -1,0 +1,176 @@
+// rt_dev_scene.h -- acceleration-structure layout in HBM and the closest-hit traversal (the work the reference
+// hands to the DXR driver through TraceRay, raytracing.hlsl:108-112, and
+// BuildRaytracingAccelerationStructure, raytracing.cpp:435,547).
+#pragma once
+#include "rt_dev_math.h"
+
+namespace rtd {
+
+// 64 B: one binary BVH node = the boxes of its two children + two links.  Fetched as 4 x 16 B.
+//   link >= 0 : index of an internal node
+//   link <  0 : leaf.  BLAS: ~link = (first_tri << 3) | (tri_count - 1), TLAS: ~link = instance index
+//   an absent child has the box RT_EMPTY_BOX and is never entered
+struct alignas(16) BvhNode {
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    int   c0, c1;
+    float bound;   // node 0 only: max |coordinate| of the whole tree (box-test padding)
+    int   depth;   // node 0 only: depth of the tree (stack budget check on the host)
+};
+#define RT_EMPTY_COORD 3.0e38f
+#define RT_LEAF_MAX_TRIS 4
+#define RT_STACK_MARKER ((int) 0x80000000)
+
+// 48 B: triangle in leaf order, fetched as 3 x 16 B
+struct alignas(16) TriRec {
+    float v0[3], v1[3], v2[3];
+    u32 prim_global; // primitive index in the concatenated index buffer of the BLAS (geometry order)
+    u32 geometry;    // GeometryIndex()
+    u32 prim_local;  // PrimitiveIndex()
+};
+
+// 64 B: what traversal needs per instance
+struct alignas(16) InstRec {
+    float world_to_object[12]; // S7
+    const BvhNode* nodes;
+    const TriRec*  tris;
+};
+
+struct SceneView {
+    const BvhNode* tlas_nodes;
+    const InstRec* insts;
+};
+
+struct HitOut {
+    float t, u, v;
+    int inst;        // TLAS leaf = index into the rt_build_tlas array, -1 = miss
+    int tri;         // TriRec index inside the instance's BLAS
+    u32 prim_global;
+};
+
+struct TraverseCounters { u32 nodes, tris, insts; };
+
+// parameters of the (non-spec, conservative) ray/box test for one level
+struct BoxRay {
+    float idx, idy, idz;   // 1 / d
+    float ox, oy, oz;      // -o / d
+    float pad;             // absolute padding in t
+};
+
+RT_DEV float fast_rcp(float x) {
+#if defined(__HIPCC__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
+RT_DEV BoxRay make_box_ray(f3 o, f3 d, float bound) {
+    BoxRay b;
+    b.idx = fast_rcp(d.x); b.idy = fast_rcp(d.y); b.idz = fast_rcp(d.z);
+    b.ox = -o.x * b.idx; b.oy = -o.y * b.idy; b.oz = -o.z * b.idz;
+    float px = (fabsf(o.x) + bound) * fabsf(b.idx);
+    float py = (fabsf(o.y) + bound) * fabsf(b.idy);
+    float pz = (fabsf(o.z) + bound) * fabsf(b.idz);
+    float pm = fminf(fminf(px, py), pz); // NaN/inf tolerant: only finite, relevant axes bound the interval
+    // a slab whose |1/d| is huge contributes an interval that is either empty or contains every t of interest;
+    // padding by the largest finite term keeps the test conservative for the other two
+    float pmax = fmaxf(fmaxf(px < 3.0e38f ? px : pm, py < 3.0e38f ? py : pm), pz < 3.0e38f ? pz : pm);
+    b.pad = pmax * 1.0e-6f;
+    return b;
+}
+
+// returns entry distance; hit iff entry <= exit
+RT_DEV bool box_test(const BoxRay& r, const float* lo, const float* hi, float tmin, float tmax, float& entry) {
+    float t0x = __builtin_fmaf(lo[0], r.idx, r.ox), t1x = __builtin_fmaf(hi[0], r.idx, r.ox);
+    float t0y = __builtin_fmaf(lo[1], r.idy, r.oy), t1y = __builtin_fmaf(hi[1], r.idy, r.oy);
+    float t0z = __builtin_fmaf(lo[2], r.idz, r.oz), t1z = __builtin_fmaf(hi[2], r.idz, r.oz);
+    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    tn = tn - r.pad - fabsf(tn) * 2.0e-6f;
+    tf = tf + r.pad + fabsf(tf) * 2.0e-6f;
+    entry = tn;
+    return fmaxf(tn, tmin) <= fminf(tf, tmax);
+}
+
+// Closest hit with TMin < t < TMax, back faces culled, ties broken by the lowest (instance, primitive) (S5, S6).
+// `Stack` provides push(int) / pop() / empty(); COUNT enables the traversal counters.
+template <class Stack, bool COUNT>
+RT_DEV void trace_closest(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, Stack& st, HitOut& best,
+                          TraverseCounters& cnt) {
+    best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.inst = -1; best.tri = -1; best.prim_global = 0;
+    bool have_hit = false;
+
+    const BvhNode* nodes = sc.tlas_nodes;
+    const TriRec* tris = nullptr;
+    BoxRay br = make_box_ray(o, d, sc.tlas_nodes[0].bound);
+    RayPrep rp; rp.o = o; rp.kx = 0; rp.ky = 1; rp.kz = 2; rp.sx = rp.sy = rp.sz = 0.0f;
+    bool bottom = false;
+    int cur_inst = -1;
+    int cur = 0;
+
+    for (;;) {
+        bool do_pop = false;
+        if (cur >= 0) {
+            const BvhNode& n = nodes[cur];
+            if (COUNT) cnt.nodes++;
+            float e0, e1;
+            bool h0 = box_test(br, n.lo0, n.hi0, tmin, best.t, e0);
+            bool h1 = box_test(br, n.lo1, n.hi1, tmin, best.t, e1);
+            int c0 = n.c0, c1 = n.c1;
+            if (h0 && h1) {
+                bool first0 = e0 <= e1;
+                st.push(first0 ? c1 : c0);
+                cur = first0 ? c0 : c1;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else do_pop = true;
+        } else if (!bottom) {
+            // TLAS leaf: enter the instance.  DXR semantics: the ray is taken to object space, t is preserved.
+            cur_inst = ~cur;
+            const InstRec& in = sc.insts[cur_inst];
+            if (COUNT) cnt.insts++;
+            f3 oo = xform_point43(in.world_to_object, o);
+            f3 od = xform_dir43(in.world_to_object, d);
+            rp = prepare_ray(oo, od);
+            nodes = in.nodes; tris = in.tris;
+            br = make_box_ray(oo, od, nodes[0].bound);
+            st.push(RT_STACK_MARKER);
+            bottom = true;
+            cur = 0;
+        } else {
+            int v = ~cur;
+            int first = v >> 3, count = (v & 7) + 1;
+            for (int k = 0; k < count; k++) {
+                const TriRec& tr = tris[first + k];
+                if (COUNT) cnt.tris++;
+                float t, u, w;
+                if (!intersect_triangle(rp, mk3(tr.v0[0], tr.v0[1], tr.v0[2]), mk3(tr.v1[0], tr.v1[1], tr.v1[2]),
+                                        mk3(tr.v2[0], tr.v2[1], tr.v2[2]), t, u, w)) continue;
+                if (!(t > tmin && t < tmax)) continue;
+                bool better = t < best.t;
+                if (!better && have_hit && t == best.t) {
+                    better = cur_inst < best.inst || (cur_inst == best.inst && tr.prim_global < best.prim_global);
+                }
+                if (better) {
+                    best.t = t; best.u = u; best.v = w; best.inst = cur_inst; best.tri = first + k;
+                    best.prim_global = tr.prim_global; have_hit = true;
+                }
+            }
+            do_pop = true;
+        }
+        if (do_pop) {
+            if (st.empty()) break;
+            cur = st.pop();
+            if (cur == RT_STACK_MARKER) {
+                bottom = false;
+                nodes = sc.tlas_nodes;
+                br = make_box_ray(o, d, sc.tlas_nodes[0].bound);
+                if (st.empty()) break;
+                cur = st.pop();
+            }
+        }
+    }
+    if (!have_hit) best.t = inf_f32();
+}
+
+} // namespace rtd
