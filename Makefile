@@ -1,0 +1,31 @@
+# Builds the three native libraries in-tree:
+#   raytracer_amd/librt_mi355x.so  HIP kernels + C-ABI (include/rt_abi.h), gfx950 only
+#   raytracer_amd/librt_host.so    CPU scene layer     (include/rt_host.h)
+#   oracle/liboracle.so            CPU golden model, test infrastructure only
+HIPCC ?= hipcc
+CXX ?= g++
+CSRC := raytracer_amd/csrc
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+            -fno-fast-math -Wall -Wno-unused-function
+HIP_SRCS := $(CSRC)/rt_api.hip $(CSRC)/rt_kernels.hip $(CSRC)/rt_bvh.hip $(CSRC)/rt_sort.hip $(CSRC)/rt_bluenoise.hip
+HIP_OBJS := $(HIP_SRCS:.hip=.o)
+HIP_HDRS := $(wildcard $(CSRC)/*.h) include/rt_abi.h
+
+all: raytracer_amd/librt_mi355x.so raytracer_amd/librt_host.so oracle/liboracle.so
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+raytracer_amd/librt_mi355x.so: $(HIP_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS)
+
+raytracer_amd/librt_host.so: raytracer_amd/host/rt_host.cpp include/rt_host.h include/rt_abi.h
+	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -shared -o $@ raytracer_amd/host/rt_host.cpp
+
+oracle/liboracle.so: oracle/rt_oracle.cpp include/rt_abi.h
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(HIP_OBJS) raytracer_amd/librt_mi355x.so raytracer_amd/librt_host.so oracle/liboracle.so
+
+.PHONY: all clean

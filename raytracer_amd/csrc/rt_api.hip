@@ -1,0 +1,685 @@
+// rt_api.hip -- context, scene management and the C-ABI of librt_mi355x.so (include/rt_abi.h).
+// Host logic mirrors src/raytracing.cpp of the reference (build_blas :316-444, build_tlas :446-551,
+// generate_translucent_samples :553-650, dispatch_rays :652-747) with HIP memory and streams in place of D3D12.
+#include "rt_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+using namespace rtd;
+using namespace rti;
+
+namespace rti {
+static thread_local char g_error[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+}
+} // namespace rti
+
+namespace {
+
+struct TranslucentMesh { // raytracing.cpp:49-53 + BluenoisePreprocess (bluenoise.h:6-12)
+    int blas;
+    u32 ib_offset, indices_count;
+    float total_surface_area;
+    float aabb_min[3], aabb_max[3];
+    float* d_partial_areas;
+};
+
+struct Blas {
+    RtVertex* d_verts = nullptr; uint16_t* d_indices = nullptr; GeomRec* d_geoms = nullptr; u32* d_tri_geometry = nullptr;
+    BvhNode* d_nodes = nullptr; TriRec* d_tris = nullptr; u32* d_perm = nullptr;
+    std::vector<RtVertex> verts; std::vector<uint16_t> indices; std::vector<GeomRec> geoms;
+    u32 n_tris = 0; int depth = 0;
+    u32 translucent_ids_index = 0, translucent_ids_count = 0;
+};
+
+struct TranslucentInstance { // raytracing.cpp:54-65
+    u32 translucent_id, instance_id;
+    float transform[16];
+    float scale_factor;
+    u32 samples_count;
+};
+
+template <typename T> void dev_free(T*& p) { if (p) { (void) hipFree(p); p = nullptr; } }
+
+} // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    LbvhWorkspace lbvh;
+    std::vector<Blas> blas;
+    std::vector<TranslucentMesh> translucent_meshes;
+    std::vector<float> translucent_mean_area; // g_translucent_properties
+    std::vector<TranslucentInstance> translucent_instances;
+    // TLAS
+    u32 n_instances = 0;
+    InstRec* d_inst_rec = nullptr; InstShade* d_inst_shade = nullptr; BvhNode* d_tlas_nodes = nullptr; u32* d_tlas_perm = nullptr;
+    int tlas_depth = 0;
+    // translucent sample points, all instances concatenated
+    u32 n_points = 0;
+    RtSamplePoint *d_sp_read = nullptr, *d_sp_write = nullptr; float* d_sp_normal = nullptr; u32* d_sp_slice = nullptr;
+    TranslucentSlice* d_slices = nullptr; int* d_slot_to_ti = nullptr; u32 slot_count = 0;
+    std::vector<TranslucentSlice> slices;
+    // frame state
+    RtGlobals g; u32 flags = RT_FLAG_COLLECT_SAMPLES | RT_FLAG_ENABLE_SSS;
+    u32 width = 0, height = 0;
+    float* d_accumulator = nullptr; uint8_t* d_render_target = nullptr;
+    RtHit* d_capture = nullptr; size_t capture_records = 0; u32 capture_bounces = 0;
+    u32 tile_rank = 0, tile_world = 1;
+    // path buffers
+    u32 n_paths = 0; float* d_arena = nullptr;
+    RayQueue q[2]; HitBuf hits; PathState ps; GatherQueue gq;
+    u32* d_qcount = nullptr; DeviceStats* d_stats = nullptr;
+    // BSSRDF tables
+    float* d_table[2] = { nullptr, nullptr }; int table_texels[2] = { 0, 0 }; int profile = 0;
+    // stats
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed; double traverse_ms = 0; uint64_t traverse_launches = 0;
+    double blas_build_ms = 0, tlas_build_ms = 0; uint64_t blas_triangles = 0;
+    rt_ctx() { memset(&g, 0, sizeof g); memset(q, 0, sizeof q); memset(&hits, 0, sizeof hits); memset(&ps, 0, sizeof ps); memset(&gq, 0, sizeof gq); }
+};
+
+namespace {
+
+// S7: world->object from object->world, in double (cofactors), rounded once
+void invert_affine(const float* m, float* inv) {
+    double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    double A = e * i - f * h, B = c * h - b * i, C = b * f - c * e;
+    double D = f * g - d * i, E = a * i - c * g, F = c * d - a * f;
+    double G = d * h - e * g, H = b * g - a * h, I = a * e - b * d;
+    double det = a * A + b * D + c * G;
+    double r[9] = { A / det, B / det, C / det, D / det, E / det, F / det, G / det, H / det, I / det };
+    double tx = m[12], ty = m[13], tz = m[14];
+    double it[3];
+    for (int j = 0; j < 3; j++) it[j] = -(tx * r[0 + j] + ty * r[3 + j] + tz * r[6 + j]);
+    for (int k = 0; k < 9; k++) inv[k] = (float) r[k];
+    for (int j = 0; j < 3; j++) inv[9 + j] = (float) it[j];
+}
+
+int ensure_path_buffers(rt_ctx* c) {
+    u32 need = std::max(c->width * c->height, c->n_points);
+    if (need == 0) need = 64;
+    if (need <= c->n_paths) return RT_OK;
+    dev_free(c->d_arena);
+    const int n_arrays = 14 /* 2 queues x (6 + path) */ + 5 /* hits */ + 15 /* path state */ + 9 /* gather */;
+    size_t stride = ((size_t) need + 63) & ~(size_t) 63;
+    RT_HIP(hipMalloc(&c->d_arena, stride * 4 * n_arrays));
+    float* p = c->d_arena;
+    auto take = [&]() { float* r = p; p += stride; return r; };
+    for (int k = 0; k < 2; k++) {
+        c->q[k].ox = take(); c->q[k].oy = take(); c->q[k].oz = take();
+        c->q[k].dx = take(); c->q[k].dy = take(); c->q[k].dz = take(); c->q[k].path = (u32*) take();
+    }
+    c->hits.t = take(); c->hits.u = take(); c->hits.v = take(); c->hits.inst = (int*) take(); c->hits.tri = (int*) take();
+    c->ps.rng = (u32*) take();
+    c->ps.thr_x = take(); c->ps.thr_y = take(); c->ps.thr_z = take();
+    c->ps.rad_x = take(); c->ps.rad_y = take(); c->ps.rad_z = take(); c->ps.alpha = take();
+    c->ps.fd_x = take(); c->ps.fd_y = take(); c->ps.fd_z = take();
+    c->ps.sum_x = take(); c->ps.sum_y = take(); c->ps.sum_z = take(); c->ps.sum_a = take();
+    c->gq.path = (u32*) take(); c->gq.hx = take(); c->gq.hy = take(); c->gq.hz = take(); c->gq.tf = take();
+    c->gq.kx = take(); c->gq.ky = take(); c->gq.kz = take(); c->gq.ti = (int*) take();
+    c->n_paths = need;
+    return RT_OK;
+}
+
+void free_sample_points(rt_ctx* c) {
+    dev_free(c->d_sp_read); dev_free(c->d_sp_write); dev_free(c->d_sp_normal); dev_free(c->d_sp_slice);
+    dev_free(c->d_slices); dev_free(c->d_slot_to_ti);
+    c->n_points = 0; c->slot_count = 0; c->slices.clear();
+}
+
+void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
+    memset(&a, 0, sizeof a);
+    a.g = c->g;
+    a.fudge = (c->flags & RT_FLAG_ENABLE_SSS) ? c->g.translucent_bssrdf_fudge : 0.0f;
+    a.width = c->width; a.height = c->height;
+    a.tile_rank = c->tile_rank; a.tile_world = c->tile_world;
+    a.tiles_x = (c->width + 31) / 32; a.tiles_y = (c->height + 31) / 32;
+    u32 n_tiles = a.tiles_x * a.tiles_y;
+    a.n_local_tiles = n_tiles > c->tile_rank ? (n_tiles - c->tile_rank + c->tile_world - 1) / c->tile_world : 0;
+    a.n_paths = c->n_paths;
+    a.probe = probe ? 1u : 0u;
+    a.tmin = probe ? 0.0001f : 0.000001f; // raytracing.hlsl:249 / :133
+    a.tmax = 10000.0f;
+    a.scene.tlas_nodes = c->d_tlas_nodes; a.scene.insts = c->d_inst_rec;
+    a.shade.insts = c->d_inst_shade; a.shade.slot_to_ti = c->d_slot_to_ti; a.shade.slot_count = c->slot_count;
+    a.shade.slices = c->d_slices;
+    a.q[0] = c->q[0]; a.q[1] = c->q[1]; a.hits = c->hits; a.ps = c->ps; a.gq = c->gq;
+    a.qcount = c->d_qcount; a.stats = c->d_stats;
+    a.capture = nullptr;
+    a.accumulator = c->d_accumulator; a.render_target = c->d_render_target;
+    a.sp_read = c->d_sp_read; a.sp_write = c->d_sp_write; a.sp_normal = c->d_sp_normal; a.sp_slice = c->d_sp_slice;
+    a.n_points = c->n_points;
+    a.bssrdf_table = c->d_table[c->profile]; a.bssrdf_texels = c->table_texels[c->profile];
+}
+
+int timed_traverse(rt_ctx* c, const PassArgs& a, u32 inq) {
+    bool timing = (c->flags & RT_FLAG_TIME_KERNELS) != 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) {
+        RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
+        RT_HIP(hipEventRecord(e0, c->stream));
+    }
+    int rc = launch_traverse(c->stream, a, inq, (c->flags & RT_FLAG_COUNT_TRAVERSAL) != 0);
+    if (timing) { RT_HIP(hipEventRecord(e1, c->stream)); c->timed.emplace_back(e0, e1); }
+    c->traverse_launches++;
+    return rc;
+}
+
+int drain_timers(rt_ctx* c) {
+    for (auto& pr : c->timed) {
+        RT_HIP(hipEventSynchronize(pr.second));
+        float ms = 0; RT_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        c->traverse_ms += ms;
+        (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second);
+    }
+    c->timed.clear();
+    return RT_OK;
+}
+
+// the loop of trace_path_sample (raytracing.hlsl:101-120) over all paths of a pass, wavefront style
+int run_pass(rt_ctx* c, bool probe) {
+    PassArgs a; fill_pass_args(c, a, probe);
+    bool capture = !probe && (c->flags & RT_FLAG_CAPTURE_HITS);
+    if (capture) {
+        size_t need = (size_t) (c->g.bounces_per_sample + 1) * c->width * c->height;
+        if (need > c->capture_records) {
+            dev_free(c->d_capture);
+            RT_HIP(hipMalloc(&c->d_capture, need * sizeof(RtHit)));
+            c->capture_records = need;
+        }
+        c->capture_bounces = c->g.bounces_per_sample + 1;
+        a.capture = c->d_capture;
+        int rc = launch_fill_capture(c->stream, a); if (rc) return rc;
+    }
+    bool gather = !probe && c->n_points > 0 && a.fudge != 0.0f;
+    for (u32 s = 0; s < c->g.samples_per_pixel; s++) {
+        RT_HIP(hipMemsetAsync(c->d_qcount, 0, 4 * sizeof(u32), c->stream));
+        int rc = probe ? launch_probe_raygen(c->stream, a, s) : launch_camera_raygen(c->stream, a, s);
+        if (rc) return rc;
+        for (u32 b = 0; b <= c->g.bounces_per_sample; b++) {
+            rc = timed_traverse(c, a, b & 1u); if (rc) return rc;
+            rc = launch_shade(c->stream, a, b & 1u, b, s); if (rc) return rc;
+            if (gather && (int) b <= c->g.translucent_emission_bounces) { rc = launch_gather(c->stream, a); if (rc) return rc; }
+        }
+    }
+    return probe ? launch_probe_resolve(c->stream, a) : launch_camera_resolve(c->stream, a);
+}
+
+float triangle_area(const float* a, const float* b, const float* c) { // geometry.cpp:21-25
+    float e1[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] }, e2[3] = { c[0] - a[0], c[1] - a[1], c[2] - a[2] };
+    float cr[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+    return 0.5f * sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+}
+
+// phase order: Fisher-Yates with xorshift32 in place of rand() (bluenoise.cpp:306-308)
+void phase_sequence(u32 seed, u32 count, u32* seq) {
+    u32 state = seed;
+    state = (state ^ 61u) ^ (state >> 16); state *= 9u; state = state ^ (state >> 4); state *= 0x27d4eb2du; state = state ^ (state >> 15);
+    state |= 1u;
+    for (u32 i = 0; i < count; i++) seq[i] = i;
+    for (u32 i = 0; i < count; i++) {
+        state ^= state << 13; state ^= state >> 17; state ^= state << 5;
+        u32 r = state % (count - i);
+        std::swap(seq[r], seq[count - 1 - i]);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_error; }
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_create(const int* devices, int n, rt_ctx** out) {
+    if (!out || !devices || n < 1) { set_error("rt_create: bad arguments"); return RT_ERR_INVALID; }
+    if (n != 1) { set_error("rt_create: one process drives one GPU (n must be 1)"); return RT_ERR_UNSUPPORTED; }
+    int count = 0;
+    RT_HIP(hipGetDeviceCount(&count));
+    if (count < 1) { set_error("rt_create: no HIP device; this library has no CPU fallback"); return RT_ERR_DEVICE; }
+    if (devices[0] < 0 || devices[0] >= count) { set_error("rt_create: device %d out of range", devices[0]); return RT_ERR_INVALID; }
+    RT_HIP(hipSetDevice(devices[0]));
+    rt_ctx* c = new rt_ctx();
+    c->device = devices[0];
+    RT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    RT_HIP(hipMalloc(&c->d_qcount, 4 * sizeof(u32)));
+    RT_HIP(hipMalloc(&c->d_stats, sizeof(DeviceStats)));
+    RT_HIP(hipMemset(c->d_qcount, 0, 4 * sizeof(u32)));
+    RT_HIP(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void) hipSetDevice(c->device);
+    (void) hipStreamSynchronize(c->stream);
+    drain_timers(c);
+    for (auto& b : c->blas) {
+        dev_free(b.d_verts); dev_free(b.d_indices); dev_free(b.d_geoms); dev_free(b.d_tri_geometry);
+        dev_free(b.d_nodes); dev_free(b.d_tris); dev_free(b.d_perm);
+    }
+    for (auto& m : c->translucent_meshes) dev_free(m.d_partial_areas);
+    free_sample_points(c);
+    dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
+    dev_free(c->d_accumulator); dev_free(c->d_render_target); dev_free(c->d_capture); dev_free(c->d_arena);
+    dev_free(c->d_qcount); dev_free(c->d_stats); dev_free(c->d_table[0]); dev_free(c->d_table[1]);
+    lbvh_workspace_free(c->lbvh);
+    if (c->own_stream) (void) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int rt_set_stream(rt_ctx* c, void* s) {
+    if (!c) return RT_ERR_INVALID;
+    RT_HIP(hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t) s : c->own_stream;
+    return RT_OK;
+}
+
+int rt_update_resolution(rt_ctx* c, uint32_t w, uint32_t h) {
+    if (!c || w == 0 || h == 0 || (uint64_t) w * h > (1ull << 28)) { set_error("rt_update_resolution: bad size"); return RT_ERR_INVALID; }
+    RT_HIP(hipSetDevice(c->device));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    dev_free(c->d_accumulator); dev_free(c->d_render_target);
+    c->width = w; c->height = h;
+    RT_HIP(hipMalloc(&c->d_accumulator, (size_t) w * h * 16));
+    RT_HIP(hipMalloc(&c->d_render_target, (size_t) w * h * 4));
+    RT_HIP(hipMemsetAsync(c->d_accumulator, 0, (size_t) w * h * 16, c->stream));
+    RT_HIP(hipMemsetAsync(c->d_render_target, 0, (size_t) w * h * 4, c->stream));
+    return ensure_path_buffers(c);
+}
+
+int rt_load_bssrdf_table(rt_ctx* c, int profile, const float* r, const float* g, const float* b, uint32_t n) {
+    if (!c || profile < 0 || profile > 1 || !r || !g || !b || n == 0) { set_error("rt_load_bssrdf_table: bad arguments"); return RT_ERR_INVALID; }
+    RT_HIP(hipSetDevice(c->device));
+    u32 padded = ((n + 255u) / 256u) * 256u; // raytracing.cpp:113
+    std::vector<float> t((size_t) padded * 3, 0.0f);
+    for (u32 i = 0; i < n; i++) { t[3 * i] = r[i]; t[3 * i + 1] = g[i]; t[3 * i + 2] = b[i]; }
+    RT_HIP(hipStreamSynchronize(c->stream));
+    dev_free(c->d_table[profile]);
+    RT_HIP(hipMalloc(&c->d_table[profile], t.size() * 4));
+    RT_HIP(hipMemcpy(c->d_table[profile], t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    c->table_texels[profile] = (int) padded;
+    return RT_OK;
+}
+
+int rt_set_bssrdf_profile(rt_ctx* c, int profile) {
+    if (!c || profile < 0 || profile > 1) return RT_ERR_INVALID;
+    c->profile = profile;
+    return RT_OK;
+}
+
+int rt_build_blas(rt_ctx* c, const RtGeometry* geometries, int n, rt_blas* out) {
+    if (!c || !geometries || n < 1 || !out) { set_error("rt_build_blas: bad arguments"); return RT_ERR_INVALID; }
+    RT_HIP(hipSetDevice(c->device));
+    Blas b;
+    b.translucent_ids_index = (u32) c->translucent_mean_area.size();
+    std::vector<u32> tri_geometry;
+    for (int gi = 0; gi < n; gi++) {
+        const RtGeometry& ge = geometries[gi];
+        if (!ge.vertices || !ge.indices || ge.index_count % 3 != 0 || ge.shader < 0 || ge.shader >= RT_SHADER_COUNT) {
+            set_error("rt_build_blas: geometry %d is malformed", gi); return RT_ERR_INVALID;
+        }
+        GeomRec rec;
+        rec.index_offset = (u32) b.indices.size(); rec.first_tri = rec.index_offset / 3;
+        rec.shader = ge.shader; rec.translucent_id = -1; // assigned below, raytracing.cpp:337
+        rec.color[0] = ge.color[0]; rec.color[1] = ge.color[1]; rec.color[2] = ge.color[2]; rec._pad = 0;
+        for (size_t k = 0; k < ge.index_count; k++) {
+            if (ge.indices[k] >= ge.vertex_count) { set_error("rt_build_blas: geometry %d index out of range", gi); return RT_ERR_INVALID; }
+            b.indices.push_back((uint16_t) (b.verts.size() + ge.indices[k])); // rebase, raytracing.cpp:360-366
+        }
+        b.verts.insert(b.verts.end(), ge.vertices, ge.vertices + ge.vertex_count);
+        for (size_t k = 0; k < ge.index_count / 3; k++) tri_geometry.push_back((u32) gi);
+        b.geoms.push_back(rec);
+    }
+    if (b.verts.size() > 65535) { set_error("rt_build_blas: %zu vertices exceed the 16-bit index range", b.verts.size()); return RT_ERR_LIMIT; } // raytracing.cpp:367
+    b.n_tris = (u32) b.indices.size() / 3;
+    if (b.n_tris == 0 || b.n_tris >= (1u << 27)) { set_error("rt_build_blas: bad triangle count %u", b.n_tris); return RT_ERR_INVALID; }
+    int blas_index = (int) c->blas.size();
+    // translucent geometries, raytracing.cpp:377-398 + Bluenoise::preprocess_mesh_data, bluenoise.cpp:69-93
+    std::vector<TranslucentMesh> new_meshes;
+    for (int gi = 0; gi < n; gi++) {
+        if (b.geoms[gi].shader != RT_SHADER_TRANSLUCENT) continue;
+        b.translucent_ids_count++;
+        b.geoms[gi].translucent_id = (int) (c->translucent_mean_area.size() + new_meshes.size());
+        TranslucentMesh m;
+        m.blas = blas_index; m.ib_offset = b.geoms[gi].index_offset; m.indices_count = (u32) geometries[gi].index_count;
+        m.total_surface_area = 0; m.d_partial_areas = nullptr;
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int k = 0; k < 3; k++) { m.aabb_min[k] = inf; m.aabb_max[k] = -inf; }
+        std::vector<float> partial;
+        for (u32 i = 0; i < m.indices_count / 3; i++) {
+            const float* p[3];
+            for (int k = 0; k < 3; k++) p[k] = b.verts[b.indices[m.ib_offset + 3 * i + k]].position;
+            m.total_surface_area += triangle_area(p[0], p[1], p[2]);
+            partial.push_back(m.total_surface_area);
+            for (int k = 0; k < 3; k++) for (int x = 0; x < 3; x++) {
+                m.aabb_min[x] = std::min(m.aabb_min[x], p[k][x]); m.aabb_max[x] = std::max(m.aabb_max[x], p[k][x]);
+            }
+        }
+        if (!partial.empty()) {
+            RT_HIP(hipMalloc(&m.d_partial_areas, partial.size() * 4));
+            RT_HIP(hipMemcpy(m.d_partial_areas, partial.data(), partial.size() * 4, hipMemcpyHostToDevice));
+        }
+        new_meshes.push_back(m);
+    }
+    // upload + build
+    hipEvent_t e0, e1;
+    RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
+    u32 n_nodes = b.n_tris > 1 ? b.n_tris - 1 : 1;
+    RT_HIP(hipMalloc(&b.d_verts, b.verts.size() * sizeof(RtVertex)));
+    RT_HIP(hipMalloc(&b.d_indices, b.indices.size() * sizeof(uint16_t)));
+    RT_HIP(hipMalloc(&b.d_geoms, b.geoms.size() * sizeof(GeomRec)));
+    RT_HIP(hipMalloc(&b.d_tri_geometry, tri_geometry.size() * 4));
+    RT_HIP(hipMalloc(&b.d_nodes, n_nodes * sizeof(BvhNode)));
+    RT_HIP(hipMalloc(&b.d_tris, b.n_tris * sizeof(TriRec)));
+    RT_HIP(hipMalloc(&b.d_perm, b.n_tris * 4));
+    RT_HIP(hipMemcpyAsync(b.d_verts, b.verts.data(), b.verts.size() * sizeof(RtVertex), hipMemcpyHostToDevice, c->stream));
+    RT_HIP(hipMemcpyAsync(b.d_indices, b.indices.data(), b.indices.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    RT_HIP(hipMemcpyAsync(b.d_geoms, b.geoms.data(), b.geoms.size() * sizeof(GeomRec), hipMemcpyHostToDevice, c->stream));
+    RT_HIP(hipMemcpyAsync(b.d_tri_geometry, tri_geometry.data(), tri_geometry.size() * 4, hipMemcpyHostToDevice, c->stream));
+    int rc = lbvh_workspace_reserve(c->lbvh, b.n_tris); if (rc) return rc;
+    RT_HIP(hipEventRecord(e0, c->stream));
+    rc = lbvh_triangle_boxes(c->stream, c->lbvh, b.d_verts, b.d_indices, b.n_tris); if (rc) return rc;
+    rc = lbvh_build(c->stream, c->lbvh, b.n_tris, RT_LEAF_MAX_TRIS, false, b.d_nodes, b.d_perm); if (rc) return rc;
+    rc = lbvh_write_trirecs(c->stream, b.d_perm, b.d_verts, b.d_indices, b.d_tri_geometry, b.d_geoms, b.n_tris, b.d_tris); if (rc) return rc;
+    RT_HIP(hipEventRecord(e1, c->stream));
+    BvhNode root;
+    RT_HIP(hipMemcpyAsync(&root, b.d_nodes, sizeof root, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(hipStreamSynchronize(c->stream)); // host arrays are borrowed only for this call
+    float ms = 0; RT_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    c->blas_build_ms = ms;
+    b.depth = root.depth;
+    c->blas_triangles += b.n_tris;
+    for (auto& m : new_meshes) { c->translucent_meshes.push_back(m); c->translucent_mean_area.push_back(0.0f); }
+    c->blas.push_back(std::move(b));
+    *out = blas_index;
+    return RT_OK;
+}
+
+int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
+    if (!c || !instances || n < 1) { set_error("rt_build_tlas: bad arguments"); return RT_ERR_INVALID; }
+    RT_HIP(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++)
+        if (instances[i].blas < 0 || instances[i].blas >= (int) c->blas.size()) { set_error("rt_build_tlas: instance %d has a bad BLAS handle", i); return RT_ERR_INVALID; }
+    RT_HIP(hipStreamSynchronize(c->stream));
+    // reset translucent mesh instances, raytracing.cpp:451-461
+    free_sample_points(c);
+    c->translucent_instances.clear();
+    c->g.translucent_instance_stride = 0;
+    std::vector<u32> counts(c->blas.size(), 0);
+    std::vector<InstRec> rec(n); std::vector<InstShade> shade(n);
+    int max_blas_depth = 0;
+    for (int i = 0; i < n; i++) {
+        const Blas& b = c->blas[instances[i].blas];
+        counts[instances[i].blas] += 1;
+        u32 instance_id = counts[instances[i].blas] - 1; // raytracing.cpp:472-479
+        if (b.translucent_ids_count > 0) {
+            for (u32 j = 0; j < b.translucent_ids_count; j++) {
+                TranslucentInstance ti;
+                ti.translucent_id = b.translucent_ids_index + j; ti.instance_id = instance_id;
+                memcpy(ti.transform, instances[i].transform, 64); ti.scale_factor = 0; ti.samples_count = 0;
+                c->translucent_instances.push_back(ti);
+            }
+            c->g.translucent_instance_stride = std::max(c->g.translucent_instance_stride, counts[instances[i].blas]);
+        }
+        invert_affine(instances[i].transform, rec[i].world_to_object);
+        rec[i].nodes = b.d_nodes; rec[i].tris = b.d_tris;
+        memcpy(shade[i].object_to_world, instances[i].transform, 64);
+        shade[i].vertices = b.d_verts; shade[i].indices = b.d_indices; shade[i].geoms = b.d_geoms; shade[i].tris = b.d_tris;
+        shade[i].instance_id = instance_id; shade[i]._pad = 0;
+        max_blas_depth = std::max(max_blas_depth, b.depth);
+    }
+    dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
+    u32 n_nodes = n > 1 ? (u32) n - 1 : 1;
+    RT_HIP(hipMalloc(&c->d_inst_rec, sizeof(InstRec) * n));
+    RT_HIP(hipMalloc(&c->d_inst_shade, sizeof(InstShade) * n));
+    RT_HIP(hipMalloc(&c->d_tlas_nodes, sizeof(BvhNode) * n_nodes));
+    RT_HIP(hipMalloc(&c->d_tlas_perm, 4 * (size_t) n));
+    RT_HIP(hipMemcpyAsync(c->d_inst_rec, rec.data(), sizeof(InstRec) * n, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(hipMemcpyAsync(c->d_inst_shade, shade.data(), sizeof(InstShade) * n, hipMemcpyHostToDevice, c->stream));
+    int rc = lbvh_workspace_reserve(c->lbvh, (u32) n); if (rc) return rc;
+    hipEvent_t e0, e1;
+    RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
+    RT_HIP(hipEventRecord(e0, c->stream));
+    rc = lbvh_instance_boxes(c->stream, c->lbvh, c->d_inst_shade, c->d_inst_rec, (u32) n); if (rc) return rc;
+    rc = lbvh_build(c->stream, c->lbvh, (u32) n, 1, true, c->d_tlas_nodes, c->d_tlas_perm); if (rc) return rc;
+    RT_HIP(hipEventRecord(e1, c->stream));
+    BvhNode root;
+    RT_HIP(hipMemcpyAsync(&root, c->d_tlas_nodes, sizeof root, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0; RT_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    c->tlas_build_ms = ms;
+    c->tlas_depth = root.depth;
+    c->n_instances = (u32) n;
+    if (c->tlas_depth + 1 + max_blas_depth > 64) {
+        set_error("rt_build_tlas: BVH too deep for the traversal stack (tlas %d + blas %d)", c->tlas_depth, max_blas_depth);
+        c->n_instances = 0;
+        return RT_ERR_LIMIT;
+    }
+    return RT_OK;
+}
+
+int rt_generate_translucent_samples(rt_ctx* c, float radius, uint32_t rng_seed, uint32_t phase_seed, uint32_t* total) {
+    if (!c || !total || !(radius > 0.0f)) { set_error("rt_generate_translucent_samples: bad arguments"); return RT_ERR_INVALID; }
+    *total = 0;
+    if (c->n_instances == 0) { set_error("rt_generate_translucent_samples: call rt_build_tlas first"); return RT_ERR_STATE; }
+    if (c->g.translucent_instance_stride == 0) return RT_OK; // raytracing.cpp:554
+    RT_HIP(hipSetDevice(c->device));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    free_sample_points(c);
+    u32 stride = c->g.translucent_instance_stride;
+    c->slot_count = (u32) c->translucent_mean_area.size() * stride;
+    std::vector<int> slot_to_ti(c->slot_count, -1);
+    std::vector<RtSamplePoint*> d_points(c->translucent_instances.size(), nullptr);
+    std::vector<float*> d_normals(c->translucent_instances.size(), nullptr);
+    u32 n_total = 0;
+    int status = RT_OK;
+    for (size_t i = 0; i < c->translucent_instances.size() && status == RT_OK; i++) {
+        TranslucentInstance& ti = c->translucent_instances[i];
+        const TranslucentMesh& mesh = c->translucent_meshes[ti.translucent_id];
+        const Blas& b = c->blas[mesh.blas];
+        BluenoiseParams p; memset(&p, 0, sizeof p);
+        p.rng_seed = rng_seed + (u32) i;
+        p.indices_offset = mesh.ib_offset;
+        p.triangles_count = mesh.indices_count / 3;
+        p.total_surface_area = mesh.total_surface_area;
+        memcpy(p.transform, ti.transform, 64);
+        { // define cell grid, bluenoise.cpp:119-147
+            float scale = 0;
+            for (int r = 0; r < 3; r++) { const float* row = &ti.transform[4 * r]; scale += sqrtf(row[0] * row[0] + row[1] * row[1] + row[2] * row[2]); }
+            scale /= 3;
+            ti.scale_factor = scale;
+            p.rejection_radius = radius / scale;
+            p.grid_cell_width = (float) ((double) p.rejection_radius / sqrt(3.0));
+            float dims[3];
+            for (int k = 0; k < 3; k++) {
+                float size = mesh.aabb_max[k] - mesh.aabb_min[k];
+                dims[k] = ceilf(size / p.grid_cell_width + 0.5f);
+                p.grid_origin[k] = mesh.aabb_min[k] - 0.5f * (p.grid_cell_width * dims[k] - size);
+                p.grid_dims[k] = (u32) dims[k];
+            }
+            double rr = p.rejection_radius;
+            double ub = ceil((double) mesh.total_surface_area / (0.5 * 6.28318530717958647692528676655900577 * 0.25 * rr * rr));
+            if (!(ub >= 1.0) || ub > 1.0e7 || (double) p.grid_dims[0] * p.grid_dims[1] * p.grid_dims[2] > 2.0e9) {
+                set_error("rt_generate_translucent_samples: radius %g gives an unreasonable point budget", radius);
+                status = RT_ERR_LIMIT; break;
+            }
+            u32 upper = (u32) ub;
+            p.initial_count = 1;
+            while (p.initial_count < 16 * upper) p.initial_count *= 2;
+            p.buckets = upper;
+        }
+        p.phases = (c->flags & RT_FLAG_ALL_PHASE_GROUPS) ? 27u : 24u;
+        phase_sequence(phase_seed, p.phases, p.phase_sequence);
+        u32 count = 0;
+        status = bluenoise_generate(c->stream, p, b.d_verts, b.d_indices, mesh.d_partial_areas, &d_points[i], &d_normals[i], &count);
+        if (status != RT_OK) break;
+        ti.samples_count = count;
+        float mean_area = ti.scale_factor * ti.scale_factor * mesh.total_surface_area / (float) count; // raytracing.cpp:595
+        c->translucent_mean_area[ti.translucent_id] = mean_area;
+        TranslucentSlice sl; sl.offset = n_total; sl.count = count;
+        sl.slot = ti.translucent_id * stride + ti.instance_id; sl.mean_area = mean_area;
+        c->slices.push_back(sl);
+        slot_to_ti[sl.slot] = (int) i;
+        n_total += count;
+    }
+    if (status == RT_OK && n_total > 0) {
+        c->n_points = n_total;
+        hipError_t e = hipSuccess;
+        if ((e = hipMalloc(&c->d_sp_read, sizeof(RtSamplePoint) * n_total)) != hipSuccess ||
+            (e = hipMalloc(&c->d_sp_write, sizeof(RtSamplePoint) * n_total)) != hipSuccess ||
+            (e = hipMalloc(&c->d_sp_normal, 12 * (size_t) n_total)) != hipSuccess ||
+            (e = hipMalloc(&c->d_sp_slice, 4 * (size_t) n_total)) != hipSuccess) {
+            set_error("hipMalloc failed: %s", hipGetErrorString(e)); status = RT_ERR_DEVICE;
+        }
+        std::vector<u32> slice_of(n_total);
+        for (size_t i = 0; i < c->slices.size() && status == RT_OK; i++) {
+            const TranslucentSlice& sl = c->slices[i];
+            if (!sl.count) continue;
+            for (u32 k = 0; k < sl.count; k++) slice_of[sl.offset + k] = (u32) i;
+            if (hipMemcpyAsync(c->d_sp_read + sl.offset, d_points[i], sizeof(RtSamplePoint) * sl.count, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+                hipMemcpyAsync(c->d_sp_write + sl.offset, d_points[i], sizeof(RtSamplePoint) * sl.count, hipMemcpyDeviceToDevice, c->stream) != hipSuccess || // clone, raytracing.cpp:607-621
+                hipMemcpyAsync(c->d_sp_normal + 3 * (size_t) sl.offset, d_normals[i], 12 * (size_t) sl.count, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
+                set_error("sample point copy failed"); status = RT_ERR_DEVICE;
+            }
+        }
+        if (status == RT_OK && hipMemcpyAsync(c->d_sp_slice, slice_of.data(), 4 * (size_t) n_total, hipMemcpyHostToDevice, c->stream) != hipSuccess) status = RT_ERR_DEVICE;
+        if (status == RT_OK) (void) hipStreamSynchronize(c->stream);
+    }
+    if (status == RT_OK && !c->slices.empty()) {
+        if (hipMalloc(&c->d_slices, sizeof(TranslucentSlice) * c->slices.size()) != hipSuccess ||
+            hipMalloc(&c->d_slot_to_ti, 4 * (size_t) std::max<u32>(c->slot_count, 1)) != hipSuccess ||
+            hipMemcpy(c->d_slices, c->slices.data(), sizeof(TranslucentSlice) * c->slices.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->d_slot_to_ti, slot_to_ti.data(), 4 * (size_t) c->slot_count, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("translucent table upload failed"); status = RT_ERR_DEVICE;
+        }
+    }
+    for (auto p : d_points) if (p) (void) hipFree(p);
+    for (auto p : d_normals) if (p) (void) hipFree(p);
+    if (status != RT_OK) { free_sample_points(c); return status; }
+    *total = n_total;
+    return ensure_path_buffers(c);
+}
+
+int rt_set_globals(rt_ctx* c, const RtGlobals* g) {
+    if (!c || !g) return RT_ERR_INVALID;
+    u32 stride = c->g.translucent_instance_stride;
+    c->g = *g;
+    c->g.translucent_instance_stride = stride;
+    return RT_OK;
+}
+int rt_get_globals(rt_ctx* c, RtGlobals* g) { if (!c || !g) return RT_ERR_INVALID; *g = c->g; return RT_OK; }
+int rt_set_flags(rt_ctx* c, uint32_t flags) { if (!c) return RT_ERR_INVALID; c->flags = flags; return RT_OK; }
+
+int rt_set_tile_split(rt_ctx* c, uint32_t rank, uint32_t world) {
+    if (!c || world == 0 || rank >= world) { set_error("rt_set_tile_split: bad rank/world"); return RT_ERR_INVALID; }
+    c->tile_rank = rank; c->tile_world = world;
+    return RT_OK;
+}
+
+int rt_dispatch_rays(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    if (c->width == 0 || c->n_instances == 0) { set_error("rt_dispatch_rays: needs rt_update_resolution and rt_build_tlas first"); return RT_ERR_STATE; }
+    if (c->g.samples_per_pixel == 0 || c->g.bounces_per_sample > 64) { set_error("rt_dispatch_rays: samples_per_pixel must be >= 1 and bounces <= 64"); return RT_ERR_INVALID; }
+    if (c->g.translucent_bssrdf_scale != 0.0f && c->n_points > 0 && !c->d_table[c->profile]) {
+        set_error("rt_dispatch_rays: tabulated BSSRDF selected but profile %d was never loaded", c->profile); return RT_ERR_STATE;
+    }
+    RT_HIP(hipSetDevice(c->device));
+    int rc = ensure_path_buffers(c); if (rc) return rc;
+    bool collect = (c->flags & RT_FLAG_COLLECT_SAMPLES) && c->n_points > 0;
+    if (collect) { rc = run_pass(c, true); if (rc) return rc; }                       // raytracing.cpp:677-687
+    if (c->flags & RT_FLAG_DOUBLE_DISPATCH) { rc = run_pass(c, false); if (rc) return rc; } // :688-695
+    if (collect) RT_HIP(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream)); // :723-728
+    rc = run_pass(c, false); if (rc) return rc;                                       // :734-741
+    c->g.accumulator_count += 1;                                                      // :744
+    c->g.translucent_accumulator_count += (c->flags & RT_FLAG_COLLECT_SAMPLES) ? 1u : 0u; // :745
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    RT_HIP(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_read_accumulator(rt_ctx* c, float* rgba) {
+    if (!c || !rgba || !c->d_accumulator) return RT_ERR_INVALID;
+    RT_HIP(hipMemcpyAsync(rgba, c->d_accumulator, (size_t) c->width * c->height * 16, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+int rt_read_render_target(rt_ctx* c, uint8_t* rgba8) {
+    if (!c || !rgba8 || !c->d_render_target) return RT_ERR_INVALID;
+    RT_HIP(hipMemcpyAsync(rgba8, c->d_render_target, (size_t) c->width * c->height * 4, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+int rt_read_hit_records(rt_ctx* c, uint32_t bounce, RtHit* out) {
+    if (!c || !out || !c->d_capture || bounce >= c->capture_bounces) { set_error("rt_read_hit_records: nothing captured for bounce %u", bounce); return RT_ERR_INVALID; }
+    size_t n = (size_t) c->width * c->height;
+    RT_HIP(hipMemcpyAsync(out, c->d_capture + bounce * n, n * sizeof(RtHit), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+int rt_translucent_instance_count(rt_ctx* c, uint32_t* n) { if (!c || !n) return RT_ERR_INVALID; *n = (u32) c->translucent_instances.size(); return RT_OK; }
+int rt_sample_point_count(rt_ctx* c, uint32_t instance, uint32_t* n) {
+    if (!c || !n || instance >= c->translucent_instances.size()) return RT_ERR_INVALID;
+    *n = c->translucent_instances[instance].samples_count; return RT_OK;
+}
+int rt_read_sample_points(rt_ctx* c, uint32_t instance, RtSamplePoint* points, float* normals) {
+    if (!c || instance >= c->slices.size()) return RT_ERR_INVALID;
+    const TranslucentSlice& sl = c->slices[instance];
+    if (points) RT_HIP(hipMemcpyAsync(points, c->d_sp_read + sl.offset, sizeof(RtSamplePoint) * sl.count, hipMemcpyDeviceToHost, c->stream));
+    if (normals) RT_HIP(hipMemcpyAsync(normals, c->d_sp_normal + 3 * (size_t) sl.offset, 12 * (size_t) sl.count, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_get_stats(rt_ctx* c, RtStats* out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    RT_HIP(hipStreamSynchronize(c->stream));
+    int rc = drain_timers(c); if (rc) return rc;
+    DeviceStats ds;
+    RT_HIP(hipMemcpy(&ds, c->d_stats, sizeof ds, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->rays_camera = ds.rays_camera; out->rays_probe = ds.rays_probe; out->gather_pairs = ds.gather_pairs;
+    out->nodes_visited = ds.nodes; out->tris_tested = ds.tris; out->instances_entered = ds.insts;
+    out->traverse_launches = c->traverse_launches; out->traverse_ms = c->traverse_ms;
+    out->blas_build_ms = c->blas_build_ms; out->tlas_build_ms = c->tlas_build_ms;
+    out->blas_triangles = c->blas_triangles; out->tlas_instances = c->n_instances;
+    return RT_OK;
+}
+int rt_reset_stats(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    RT_HIP(hipStreamSynchronize(c->stream));
+    int rc = drain_timers(c); if (rc) return rc;
+    RT_HIP(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
+    c->traverse_ms = 0; c->traverse_launches = 0;
+    return RT_OK;
+}
+
+int rt_accumulator_device_ptr(rt_ctx* c, void** dev_ptr, size_t* bytes) {
+    if (!c || !dev_ptr || !bytes || !c->d_accumulator) return RT_ERR_INVALID;
+    *dev_ptr = c->d_accumulator; *bytes = (size_t) c->width * c->height * 16;
+    return RT_OK;
+}
+
+int rt_resolve_render_target(rt_ctx* c) {
+    if (!c || !c->d_accumulator) return RT_ERR_INVALID;
+    PassArgs a; fill_pass_args(c, a, false);
+    return launch_resolve_only(c->stream, a);
+}
+
+} // extern "C"

@@ -1,0 +1,254 @@
+// rt_bvh.hip -- GPU LBVH build for the bottom level (triangles) and top level (instances).
+// Replaces the DXR driver builds issued at raytracing.cpp:411-436 (BLAS) and raytracing.cpp:523-548 (TLAS).
+//
+// Pipeline: primitive boxes -> scene bounds -> 30-bit Morton codes -> stable radix sort -> Karras 2012
+// hierarchy -> bottom-up refit with arrival counters -> 64-byte two-child traversal nodes with leaves of up to
+// RT_LEAF_MAX_TRIS triangles.
+#include "rt_internal.h"
+
+namespace rti {
+
+using namespace rtd;
+
+static constexpr int BT = 256;
+static inline dim3 grid_for(u32 n, int bt = BT) { return dim3((n + bt - 1) / bt); }
+
+__global__ void k_triangle_boxes(const RtVertex* __restrict__ verts, const uint16_t* __restrict__ indices, u32 n,
+                                 Aabb* __restrict__ boxes) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Aabb b;
+    for (int k = 0; k < 3; k++) { b.lo[k] = 3.4e38f; b.hi[k] = -3.4e38f; }
+    for (int c = 0; c < 3; c++) {
+        const float* p = verts[indices[3 * i + c]].position;
+        for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], p[k]); b.hi[k] = fmaxf(b.hi[k], p[k]); }
+    }
+    boxes[i] = b;
+}
+
+__global__ void k_instance_boxes(const InstShade* __restrict__ shade, const InstRec* __restrict__ insts, u32 n,
+                                 Aabb* __restrict__ boxes) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const BvhNode& root = insts[i].nodes[0];
+    // object-space box of the whole BLAS = union of the root's two child boxes
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {
+        lo[k] = root.lo0[k]; hi[k] = root.hi0[k];
+        if (root.lo1[k] != RT_EMPTY_COORD) { lo[k] = fminf(lo[k], root.lo1[k]); hi[k] = fmaxf(hi[k], root.hi1[k]); }
+    }
+    Aabb b;
+    for (int k = 0; k < 3; k++) { b.lo[k] = 3.4e38f; b.hi[k] = -3.4e38f; }
+    float amax = 0.0f;
+    for (int c = 0; c < 8; c++) {
+        f3 p = mk3((c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]);
+        f3 w = xform_point44(shade[i].object_to_world, p);
+        float wv[3] = { w.x, w.y, w.z };
+        for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], wv[k]); b.hi[k] = fmaxf(b.hi[k], wv[k]); amax = fmaxf(amax, fabsf(wv[k])); }
+    }
+    // the world-space box test and the object-space triangle test round differently: pad generously
+    float pad = amax * 1.0e-5f + 1.0e-30f;
+    for (int k = 0; k < 3; k++) { b.lo[k] -= pad; b.hi[k] += pad; }
+    boxes[i] = b;
+}
+
+// one workgroup: union of all boxes
+__global__ __launch_bounds__(1024) void k_scene_box(const Aabb* __restrict__ boxes, u32 n, Aabb* __restrict__ out) {
+    __shared__ float slo[3][1024], shi[3][1024];
+    float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+    for (u32 i = threadIdx.x; i < n; i += 1024)
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], boxes[i].lo[k]); hi[k] = fmaxf(hi[k], boxes[i].hi[k]); }
+    for (int k = 0; k < 3; k++) { slo[k][threadIdx.x] = lo[k]; shi[k][threadIdx.x] = hi[k]; }
+    __syncthreads();
+    for (u32 off = 512; off >= 1; off >>= 1) {
+        if (threadIdx.x < off)
+            for (int k = 0; k < 3; k++) {
+                slo[k][threadIdx.x] = fminf(slo[k][threadIdx.x], slo[k][threadIdx.x + off]);
+                shi[k][threadIdx.x] = fmaxf(shi[k][threadIdx.x], shi[k][threadIdx.x + off]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) for (int k = 0; k < 3; k++) { out->lo[k] = slo[k][0]; out->hi[k] = shi[k][0]; }
+}
+
+__global__ void k_morton(const Aabb* __restrict__ boxes, const Aabb* __restrict__ scene, u32 n, u32* __restrict__ keys,
+                         u32* __restrict__ vals) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = morton30(boxes[i], *scene);
+    vals[i] = i;
+}
+
+__global__ void k_hierarchy(const u32* __restrict__ keys, int n, BuildNode* __restrict__ bn, int* __restrict__ leaf_parent) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int first, last, split;
+    lbvh_node_range(keys, n, i, first, last, split);
+    int left = (split == first) ? ~split : split;
+    int right = (split + 1 == last) ? ~(split + 1) : split + 1;
+    bn[i].left = left; bn[i].right = right; bn[i].first = first; bn[i].last = last;
+    if (left < 0) leaf_parent[~left] = i; else bn[left].parent = i;
+    if (right < 0) leaf_parent[~right] = i; else bn[right].parent = i;
+    if (i == 0) bn[0].parent = -1;
+}
+
+RT_DEV float load_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// bottom-up: the second thread to arrive at a node merges its children's boxes and continues upwards
+__global__ void k_refit(const Aabb* __restrict__ boxes, const u32* __restrict__ perm, int n, const BuildNode* __restrict__ bn,
+                        const int* __restrict__ leaf_parent, Aabb* node_boxes, int* depth, u32* flags) {
+    int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= n) return;
+    int node = leaf_parent[leaf];
+    while (node >= 0) {
+        __threadfence(); // release what this thread wrote for the level below
+        u32 old = atomicAdd(&flags[node], 1u);
+        if (old == 0) return;
+        __threadfence(); // acquire the sibling's writes
+        Aabb b; int dep = 0;
+        for (int k = 0; k < 3; k++) { b.lo[k] = 3.4e38f; b.hi[k] = -3.4e38f; }
+        int child[2] = { bn[node].left, bn[node].right };
+        for (int c = 0; c < 2; c++) {
+            if (child[c] < 0) {
+                const Aabb& cb = boxes[perm[~child[c]]];
+                for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], cb.lo[k]); b.hi[k] = fmaxf(b.hi[k], cb.hi[k]); }
+            } else {
+                const Aabb* cb = &node_boxes[child[c]];
+                for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], load_agent(&cb->lo[k])); b.hi[k] = fmaxf(b.hi[k], load_agent(&cb->hi[k])); }
+                int cd = __hip_atomic_load(&depth[child[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dep = cd > dep ? cd : dep;
+            }
+        }
+        node_boxes[node] = b;
+        depth[node] = dep + 1;
+        node = bn[node].parent;
+    }
+}
+
+RT_DEV Aabb child_box(int child, const Aabb* boxes, const u32* perm, const Aabb* node_boxes) {
+    return child < 0 ? boxes[perm[~child]] : node_boxes[child];
+}
+
+__global__ void k_emit(const Aabb* __restrict__ boxes, const u32* __restrict__ perm, int n, const BuildNode* __restrict__ bn,
+                       const Aabb* __restrict__ node_boxes, const int* __restrict__ depth, const Aabb* __restrict__ scene,
+                       int leaf_max, int tlas, BvhNode* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    BvhNode nd;
+    Aabb b0 = child_box(bn[i].left, boxes, perm, node_boxes), b1 = child_box(bn[i].right, boxes, perm, node_boxes);
+    set_box(nd.lo0, nd.hi0, b0);
+    set_box(nd.lo1, nd.hi1, b1);
+    nd.c0 = lbvh_child_link(bn[i].left, bn, perm, leaf_max, tlas != 0);
+    nd.c1 = lbvh_child_link(bn[i].right, bn, perm, leaf_max, tlas != 0);
+    nd.bound = 0.0f; nd.depth = 0;
+    if (i == 0) {
+        float m = 0.0f;
+        for (int k = 0; k < 3; k++) m = fmaxf(m, fmaxf(fabsf(scene->lo[k]), fabsf(scene->hi[k])));
+        nd.bound = m; nd.depth = depth[0];
+    }
+    out[i] = nd;
+}
+
+// n <= leaf_max (or n == 1): a root whose first child is the only leaf
+__global__ void k_emit_single(const Aabb* __restrict__ scene, const u32* __restrict__ perm, int n, int tlas, BvhNode* __restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    BvhNode nd;
+    set_box(nd.lo0, nd.hi0, *scene);
+    set_empty_box(nd.lo1, nd.hi1);
+    nd.c0 = tlas ? ~((int) perm[0]) : ~((0 << 3) | (n - 1));
+    nd.c1 = nd.c0; // never entered: its box is empty
+    float m = 0.0f;
+    for (int k = 0; k < 3; k++) m = fmaxf(m, fmaxf(fabsf(scene->lo[k]), fabsf(scene->hi[k])));
+    nd.bound = m; nd.depth = 1;
+    out[0] = nd;
+}
+
+__global__ void k_trirecs(const u32* __restrict__ perm, const RtVertex* __restrict__ verts, const uint16_t* __restrict__ indices,
+                          const u32* __restrict__ tri_geometry, const GeomRec* __restrict__ geoms, u32 n, TriRec* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 prim = perm[i];
+    TriRec t;
+    const float* p0 = verts[indices[3 * prim + 0]].position;
+    const float* p1 = verts[indices[3 * prim + 1]].position;
+    const float* p2 = verts[indices[3 * prim + 2]].position;
+    for (int k = 0; k < 3; k++) { t.v0[k] = p0[k]; t.v1[k] = p1[k]; t.v2[k] = p2[k]; }
+    t.prim_global = prim;
+    t.geometry = tri_geometry[prim];
+    t.prim_local = prim - geoms[t.geometry].first_tri;
+    out[i] = t;
+}
+
+int lbvh_workspace_reserve(LbvhWorkspace& w, u32 n) {
+    if (n <= w.capacity) return RT_OK;
+    lbvh_workspace_free(w);
+    u32 cap = n < 1024 ? 1024 : n;
+    RT_HIP(hipMalloc(&w.boxes, sizeof(Aabb) * cap));
+    RT_HIP(hipMalloc(&w.node_boxes, sizeof(Aabb) * cap));
+    RT_HIP(hipMalloc(&w.scene_box, sizeof(Aabb)));
+    RT_HIP(hipMalloc(&w.keys, 4 * (size_t) cap));
+    RT_HIP(hipMalloc(&w.vals, 4 * (size_t) cap));
+    RT_HIP(hipMalloc(&w.keys_tmp, 4 * (size_t) cap));
+    RT_HIP(hipMalloc(&w.vals_tmp, 4 * (size_t) cap));
+    RT_HIP(hipMalloc(&w.build_nodes, sizeof(BuildNode) * cap));
+    RT_HIP(hipMalloc(&w.leaf_parent, 4 * (size_t) cap));
+    RT_HIP(hipMalloc(&w.flags, 4 * (size_t) cap));
+    RT_HIP(hipMalloc(&w.depth, 4 * (size_t) cap));
+    RT_HIP(hipMalloc(&w.sort_scratch, sort_scratch_bytes(cap)));
+    w.capacity = cap;
+    return RT_OK;
+}
+
+void lbvh_workspace_free(LbvhWorkspace& w) {
+    void* ptrs[] = { w.boxes, w.node_boxes, w.scene_box, w.keys, w.vals, w.keys_tmp, w.vals_tmp, w.build_nodes,
+                     w.leaf_parent, w.flags, w.depth, w.sort_scratch };
+    for (void* p : ptrs) if (p) (void) hipFree(p);
+    w = LbvhWorkspace();
+}
+
+int lbvh_triangle_boxes(hipStream_t s, LbvhWorkspace& w, const RtVertex* verts, const uint16_t* indices, u32 n_tris) {
+    if (n_tris == 0) return RT_OK;
+    hipLaunchKernelGGL(k_triangle_boxes, grid_for(n_tris), dim3(BT), 0, s, verts, indices, n_tris, w.boxes);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const InstShade* shade, const InstRec* insts, u32 n) {
+    if (n == 0) return RT_OK;
+    hipLaunchKernelGGL(k_instance_boxes, grid_for(n), dim3(BT), 0, s, shade, insts, n, w.boxes);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+int lbvh_build(hipStream_t s, LbvhWorkspace& w, u32 n, int leaf_max, bool tlas, BvhNode* nodes_out, u32* perm_out) {
+    if (n == 0 || n > w.capacity) { set_error("lbvh_build: bad primitive count %u", n); return RT_ERR_INVALID; }
+    hipLaunchKernelGGL(k_scene_box, dim3(1), dim3(1024), 0, s, w.boxes, n, w.scene_box);
+    hipLaunchKernelGGL(k_morton, grid_for(n), dim3(BT), 0, s, w.boxes, w.scene_box, n, w.keys, w.vals);
+    int rc = radix_sort_pairs(s, w.keys, w.vals, w.keys_tmp, w.vals_tmp, w.sort_scratch, n, 30);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipMemcpyAsync(perm_out, w.vals, (size_t) n * 4, hipMemcpyDeviceToDevice, s));
+    if ((int) n <= leaf_max) {
+        hipLaunchKernelGGL(k_emit_single, dim3(1), dim3(64), 0, s, w.scene_box, perm_out, (int) n, tlas ? 1 : 0, nodes_out);
+        RT_HIP(hipGetLastError());
+        return RT_OK;
+    }
+    RT_HIP(hipMemsetAsync(w.flags, 0, (size_t) n * 4, s));
+    RT_HIP(hipMemsetAsync(w.depth, 0, (size_t) n * 4, s));
+    hipLaunchKernelGGL(k_hierarchy, grid_for(n - 1), dim3(BT), 0, s, w.keys, (int) n, w.build_nodes, w.leaf_parent);
+    hipLaunchKernelGGL(k_refit, grid_for(n), dim3(BT), 0, s, w.boxes, perm_out, (int) n, w.build_nodes, w.leaf_parent,
+                       w.node_boxes, w.depth, w.flags);
+    hipLaunchKernelGGL(k_emit, grid_for(n - 1), dim3(BT), 0, s, w.boxes, perm_out, (int) n, w.build_nodes, w.node_boxes,
+                       w.depth, w.scene_box, leaf_max, tlas ? 1 : 0, nodes_out);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+int lbvh_write_trirecs(hipStream_t s, const u32* perm, const RtVertex* verts, const uint16_t* indices,
+                       const u32* tri_geometry, const GeomRec* geoms, u32 n_tris, TriRec* out) {
+    if (n_tris == 0) return RT_OK;
+    hipLaunchKernelGGL(k_trirecs, grid_for(n_tris), dim3(BT), 0, s, perm, verts, indices, tri_geometry, geoms, n_tris, out);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+} // namespace rti

@@ -1,0 +1,132 @@
+// rt_internal.h -- host-side declarations shared by the .hip translation units of librt_mi355x.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+#include "rt_dev_lbvh.h"
+#include "rt_dev_shade.h"
+
+namespace rti {
+
+using rtd::u32;
+
+void set_error(const char* fmt, ...);
+
+#define RT_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            rti::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return RT_ERR_DEVICE;                                                                 \
+        }                                                                                         \
+    } while (0)
+
+// ---- device radix sort (rt_sort.hip) -----------------------------------------------------------------------
+// stable LSD sort of (key, value) pairs on `key_bits` low bits; scratch sizes from sort_scratch_bytes
+size_t sort_scratch_bytes(u32 n);
+int radix_sort_pairs(hipStream_t s, u32* keys, u32* vals, u32* keys_tmp, u32* vals_tmp, void* scratch, u32 n,
+                     int key_bits); // result ends in keys/vals
+
+// ---- LBVH (rt_bvh.hip) ---------------------------------------------------------------------------------------
+struct LbvhWorkspace {
+    rtd::Aabb* boxes = nullptr;      // per primitive
+    rtd::Aabb* node_boxes = nullptr; // per internal node
+    rtd::Aabb* scene_box = nullptr;
+    u32 *keys = nullptr, *vals = nullptr, *keys_tmp = nullptr, *vals_tmp = nullptr;
+    rtd::BuildNode* build_nodes = nullptr;
+    int* leaf_parent = nullptr;
+    u32* flags = nullptr;
+    int* depth = nullptr;
+    void* sort_scratch = nullptr;
+    u32 capacity = 0;
+};
+int lbvh_workspace_reserve(LbvhWorkspace& w, u32 n);
+void lbvh_workspace_free(LbvhWorkspace& w);
+
+// boxes for the n triangles of a BLAS -> w.boxes
+int lbvh_triangle_boxes(hipStream_t s, LbvhWorkspace& w, const RtVertex* verts, const uint16_t* indices, u32 n_tris);
+// world boxes of n instances (8 corners of each BLAS root box through object_to_world, padded) -> w.boxes
+int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const rtd::InstShade* shade, const rtd::InstRec* insts, u32 n);
+// builds the hierarchy over w.boxes[0..n); nodes_out has max(1, n-1) entries; perm_out[n] = sorted -> original.
+int lbvh_build(hipStream_t s, LbvhWorkspace& w, u32 n, int leaf_max, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
+// TriRec array in leaf order
+int lbvh_write_trirecs(hipStream_t s, const u32* perm, const RtVertex* verts, const uint16_t* indices,
+                       const u32* tri_geometry, const rtd::GeomRec* geoms, u32 n_tris, rtd::TriRec* out);
+
+// ---- wavefront pipeline (rt_kernels.hip) ---------------------------------------------------------------------
+struct RayQueue { float *ox, *oy, *oz, *dx, *dy, *dz; u32* path; };
+struct HitBuf { float *t, *u, *v; int *inst, *tri; };
+struct PathState {
+    u32* rng;
+    float *thr_x, *thr_y, *thr_z;
+    float *rad_x, *rad_y, *rad_z, *alpha;
+    float *fd_x, *fd_y, *fd_z;           // probe pass: direction after trace_path_sample (raytracing.hlsl:258)
+    float *sum_x, *sum_y, *sum_z, *sum_a; // per-dispatch sample sum
+};
+struct GatherQueue { u32* path; float *hx, *hy, *hz, *tf, *kx, *ky, *kz; int* ti; };
+
+struct DeviceStats { // lives in device memory
+    unsigned long long rays_camera, rays_probe, gather_pairs, nodes, tris, insts;
+};
+
+struct PassArgs {
+    RtGlobals g;
+    float fudge;                 // translucent_bssrdf_fudge or 0 when SSS is disabled (raytracing.cpp:653-657)
+    u32 width, height;
+    u32 tile_rank, tile_world, tiles_x, tiles_y, n_local_tiles;
+    u32 n_paths;                 // capacity of the path arrays
+    u32 probe;                   // 1 = translucent_rgen pass
+    float tmin, tmax;
+    rtd::SceneView scene;
+    rtd::ShadeScene shade;
+    RayQueue q[2];
+    HitBuf hits;
+    PathState ps;
+    GatherQueue gq;
+    u32* qcount;                 // [0],[1] ray queue sizes, [2] gather queue size
+    DeviceStats* stats;
+    RtHit* capture;              // [(bounces+1) * width*height] or null
+    float* accumulator;          // RGBA32F
+    uint8_t* render_target;      // RGBA8
+    // translucent sample points (all instances concatenated)
+    RtSamplePoint* sp_read;
+    RtSamplePoint* sp_write;
+    const float* sp_normal;      // 3 per point
+    const u32* sp_slice;         // per point -> slice index
+    u32 n_points;
+    const float* bssrdf_table;   // rgb interleaved
+    int bssrdf_texels;
+};
+
+int launch_camera_raygen(hipStream_t s, const PassArgs& a, u32 sample_index);
+int launch_probe_raygen(hipStream_t s, const PassArgs& a, u32 sample_index);
+int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal);
+int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index);
+int launch_gather(hipStream_t s, const PassArgs& a);
+int launch_camera_resolve(hipStream_t s, const PassArgs& a);
+int launch_probe_resolve(hipStream_t s, const PassArgs& a);
+int launch_fill_capture(hipStream_t s, const PassArgs& a);
+int launch_resolve_only(hipStream_t s, const PassArgs& a); // raytracing.hlsl:161 after an external accumulator sum
+
+// ---- blue-noise sample points (rt_bluenoise.hip) ----------------------------------------------------------------
+struct BluenoiseParams { // ComputeGlobals, bluenoise.h:16-32
+    u32 rng_seed, triangles_count, indices_offset;
+    float total_surface_area;
+    float transform[16];
+    float rejection_radius;
+    float grid_origin[3];
+    float grid_cell_width;
+    u32 grid_dims[3];
+    u32 buckets;
+    u32 initial_count;
+    u32 phases;
+    u32 phase_sequence[27];
+};
+// returns the number of points; points/normals are device arrays with capacity `capacity`
+int bluenoise_generate(hipStream_t s, const BluenoiseParams& p, const RtVertex* verts, const uint16_t* indices,
+                       const float* partial_areas, RtSamplePoint** points_out, float** normals_out, u32* count_out);
+
+} // namespace rti

@@ -1,0 +1,401 @@
+// rt_kernels.hip -- the wavefront path-tracing pipeline for gfx950.
+//
+//   camera_rgen      (raytracing.hlsl:128-163)  ->  k_camera_raygen / k_camera_resolve
+//   translucent_rgen (raytracing.hlsl:224-265)  ->  k_probe_raygen  / k_probe_resolve
+//   trace_path_sample loop (raytracing.hlsl:92-126) -> per bounce: k_traverse -> k_shade [-> k_gather]
+//   TraceRay (driver)                            ->  k_traverse: one ray per lane, two-level BVH2, per-lane stack in LDS
+//   lambert/light/translucent_chit, miss         ->  k_shade
+//   translucent_chit's loop over all sample points (raytracing.hlsl:323-331) -> k_gather
+//
+// Rays live in SoA queues in HBM; a ray is (origin, direction, path id) and the hit record is 20 B.  Paths that
+// end are dropped from the next queue by a wave-aggregated append, so every traverse launch runs on a dense array.
+#include "rt_internal.h"
+
+namespace rti {
+
+using namespace rtd;
+
+static constexpr int TRAVERSE_WAVE   = 64;
+static constexpr int LDS_STACK_DEPTH = 24;  // entries per lane kept in LDS
+static constexpr int OVF_STACK_DEPTH = 40;  // spill (scratch); the host checks tlas_depth + 1 + blas_depth <= 64
+static constexpr int BT = 256;
+
+struct LaneStack {
+    int* lds;   // &smem[lane], entries are 64 ints apart (conflict-free)
+    int  ovf[OVF_STACK_DEPTH];
+    int  sp;
+    RT_DEV void push(int v) {
+        if (sp < LDS_STACK_DEPTH) lds[sp * TRAVERSE_WAVE] = v;
+        else if (sp < LDS_STACK_DEPTH + OVF_STACK_DEPTH) ovf[sp - LDS_STACK_DEPTH] = v;
+        sp++;
+    }
+    RT_DEV int pop() {
+        sp--;
+        if (sp < LDS_STACK_DEPTH) return lds[sp * TRAVERSE_WAVE];
+        if (sp < LDS_STACK_DEPTH + OVF_STACK_DEPTH) return ovf[sp - LDS_STACK_DEPTH];
+        return RT_STACK_MARKER; // unreachable when the host-side depth check holds
+    }
+    RT_DEV bool empty() const { return sp == 0; }
+};
+
+RT_DEV u32 wave_append(u32* counter, bool pred) {
+    unsigned long long m = __ballot(pred);
+    if (m == 0ull) return 0u;
+    u32 lane = __lane_id();
+    u32 rank = __popcll(m & ((1ull << lane) - 1ull));
+    int leader = __ffsll((long long) m) - 1;
+    u32 base = 0;
+    if ((int) lane == leader) base = atomicAdd(counter, (u32) __popcll(m));
+    base = __shfl(base, leader);
+    return base + rank;
+}
+
+RT_DEV u32 wave_sum(u32 v) {
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// thread -> pixel: 32x32 tiles (the multi-GPU split unit), 8x8 pixels per wave for coherent primary rays
+RT_DEV bool thread_pixel(const PassArgs& a, u32 t, u32& px, u32& py) {
+    if (t >= a.n_local_tiles * 1024u) return false;
+    u32 tile = (t >> 10) * a.tile_world + a.tile_rank;
+    u32 r = t & 1023u, sub = r >> 6, lane = r & 63u;
+    px = (tile % a.tiles_x) * 32u + (sub & 3u) * 8u + (lane & 7u);
+    py = (tile / a.tiles_x) * 32u + (sub >> 2) * 8u + (lane >> 3);
+    return px < a.width && py < a.height;
+}
+
+__global__ __launch_bounds__(BT) void k_camera_raygen(PassArgs a, u32 sample_index) {
+    u32 t = blockIdx.x * BT + threadIdx.x;
+    u32 px = 0, py = 0;
+    bool active = thread_pixel(a, t, px, py);
+    u32 pixel = py * a.width + px;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
+    if (active) {
+        u32 rng;
+        if (sample_index == 0) {
+            rng = hash_u3(px, py, a.g.frame_rng * (u32) (a.g.accumulator_count != 0)); // raytracing.hlsl:130
+            a.ps.sum_x[pixel] = 0.0f; a.ps.sum_y[pixel] = 0.0f; a.ps.sum_z[pixel] = 0.0f; a.ps.sum_a[pixel] = 0.0f;
+        } else {
+            rng = a.ps.rng[pixel];
+            a.ps.sum_x[pixel] += a.ps.rad_x[pixel]; a.ps.sum_y[pixel] += a.ps.rad_y[pixel];
+            a.ps.sum_z[pixel] += a.ps.rad_z[pixel]; a.ps.sum_a[pixel] += a.ps.alpha[pixel];
+        }
+        camera_ray(a.g, px, py, a.width, a.height, rng, o, d);
+        a.ps.rng[pixel] = rng;
+        a.ps.thr_x[pixel] = 1.0f; a.ps.thr_y[pixel] = 1.0f; a.ps.thr_z[pixel] = 1.0f;
+        a.ps.rad_x[pixel] = 0.0f; a.ps.rad_y[pixel] = 0.0f; a.ps.rad_z[pixel] = 0.0f; a.ps.alpha[pixel] = 1.0f;
+    }
+    u32 slot = wave_append(&a.qcount[0], active);
+    if (active) {
+        const RayQueue& q = a.q[0];
+        q.ox[slot] = o.x; q.oy[slot] = o.y; q.oz[slot] = o.z;
+        q.dx[slot] = d.x; q.dy[slot] = d.y; q.dz[slot] = d.z;
+        q.path[slot] = pixel;
+    }
+}
+
+__global__ __launch_bounds__(BT) void k_camera_resolve(PassArgs a) {
+    u32 t = blockIdx.x * BT + threadIdx.x;
+    u32 px, py;
+    if (!thread_pixel(a, t, px, py)) return;
+    u32 pixel = py * a.width + px;
+    float acc[4];
+    acc[0] = a.ps.sum_x[pixel] + a.ps.rad_x[pixel];
+    acc[1] = a.ps.sum_y[pixel] + a.ps.rad_y[pixel];
+    acc[2] = a.ps.sum_z[pixel] + a.ps.rad_z[pixel];
+    acc[3] = a.ps.sum_a[pixel] + a.ps.alpha[pixel];
+    float spp = (float) a.g.samples_per_pixel;
+    float4 prev = make_float4(0, 0, 0, 0);
+    if (a.g.accumulator_count != 0) prev = ((const float4*) a.accumulator)[pixel];
+    float pv[4] = { prev.x, prev.y, prev.z, prev.w };
+    float denom = (float) (a.g.accumulator_count + 1u);
+    unsigned char rt[4];
+    for (int k = 0; k < 4; k++) {
+        acc[k] = acc[k] / spp;                                   // raytracing.hlsl:153
+        if (a.g.accumulator_count != 0) acc[k] = acc[k] + pv[k]; // :155-158
+        rt[k] = to_unorm8(sqrtf(acc[k] / denom));                // :161
+    }
+    ((float4*) a.accumulator)[pixel] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    ((uchar4*) a.render_target)[pixel] = make_uchar4(rt[0], rt[1], rt[2], rt[3]);
+}
+
+// re-derives the render target from an accumulator that already holds `accumulator_count` frames
+__global__ __launch_bounds__(BT) void k_resolve_only(PassArgs a) {
+    u32 pixel = blockIdx.x * BT + threadIdx.x;
+    if (pixel >= a.width * a.height) return;
+    float4 v = ((const float4*) a.accumulator)[pixel];
+    float denom = (float) (a.g.accumulator_count == 0 ? 1u : a.g.accumulator_count);
+    ((uchar4*) a.render_target)[pixel] = make_uchar4(to_unorm8(sqrtf(v.x / denom)), to_unorm8(sqrtf(v.y / denom)),
+                                                      to_unorm8(sqrtf(v.z / denom)), to_unorm8(sqrtf(v.w / denom)));
+}
+
+RT_DEV void probe_finish_sample(const PassArgs& a, u32 p, f3 normal, f3& tsum) { // raytracing.hlsl:257-261
+    f3 radiance = mk3(a.ps.rad_x[p], a.ps.rad_y[p], a.ps.rad_z[p]);
+    f3 fd = mk3(a.ps.fd_x[p], a.ps.fd_y[p], a.ps.fd_z[p]);
+    float cosine = -dot3(fd, normal);
+    float fresnel = 1.0f - schlick(a.g.translucent_refractive_index, cosine);
+    tsum = tsum + radiance * cosine * fresnel;
+}
+
+__global__ __launch_bounds__(BT) void k_probe_raygen(PassArgs a, u32 sample_index) {
+    u32 p = blockIdx.x * BT + threadIdx.x;
+    bool active = p < a.n_points;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
+    if (active) {
+        const TranslucentSlice& sl = a.shade.slices[a.sp_slice[p]];
+        u32 x = p - sl.offset;
+        f3 normal = mk3(a.sp_normal[3 * p], a.sp_normal[3 * p + 1], a.sp_normal[3 * p + 2]);
+        u32 rng;
+        if (sample_index == 0) {
+            rng = hash_u3(x, sl.slot, a.g.frame_rng * (u32) (a.g.translucent_accumulator_count != 0)); // :246
+            a.ps.sum_x[p] = 0.0f; a.ps.sum_y[p] = 0.0f; a.ps.sum_z[p] = 0.0f;
+        } else {
+            rng = a.ps.rng[p];
+            f3 tsum = mk3(a.ps.sum_x[p], a.ps.sum_y[p], a.ps.sum_z[p]);
+            probe_finish_sample(a, p, normal, tsum);
+            a.ps.sum_x[p] = tsum.x; a.ps.sum_y[p] = tsum.y; a.ps.sum_z[p] = tsum.z;
+        }
+        const RtSamplePoint& sp = a.sp_write[p];
+        o = mk3(sp.position[0], sp.position[1], sp.position[2]);
+        d = random_on_hemisphere(rng, normal);
+        a.ps.rng[p] = rng;
+        a.ps.thr_x[p] = 1.0f; a.ps.thr_y[p] = 1.0f; a.ps.thr_z[p] = 1.0f;
+        a.ps.rad_x[p] = 0.0f; a.ps.rad_y[p] = 0.0f; a.ps.rad_z[p] = 0.0f; a.ps.alpha[p] = 1.0f;
+        a.ps.fd_x[p] = d.x; a.ps.fd_y[p] = d.y; a.ps.fd_z[p] = d.z;
+    }
+    u32 slot = wave_append(&a.qcount[0], active);
+    if (active) {
+        const RayQueue& q = a.q[0];
+        q.ox[slot] = o.x; q.oy[slot] = o.y; q.oz[slot] = o.z;
+        q.dx[slot] = d.x; q.dy[slot] = d.y; q.dz[slot] = d.z;
+        q.path[slot] = p;
+    }
+}
+
+__global__ __launch_bounds__(BT) void k_probe_resolve(PassArgs a) {
+    u32 p = blockIdx.x * BT + threadIdx.x;
+    if (p >= a.n_points) return;
+    const TranslucentSlice& sl = a.shade.slices[a.sp_slice[p]];
+    f3 normal = mk3(a.sp_normal[3 * p], a.sp_normal[3 * p + 1], a.sp_normal[3 * p + 2]);
+    f3 tsum = mk3(a.ps.sum_x[p], a.ps.sum_y[p], a.ps.sum_z[p]);
+    probe_finish_sample(a, p, normal, tsum);
+    RtSamplePoint sp = a.sp_write[p];
+    f3 payload = mk3(sp.payload[0], sp.payload[1], sp.payload[2]);
+    if (a.g.translucent_accumulator_count == 0) payload = mk3(0.0f, 0.0f, 0.0f);     // raytracing.hlsl:243
+    payload = payload + (tsum * sl.mean_area) / (RT_TAU_F / 2.0f * (float) a.g.samples_per_pixel); // :263
+    sp.payload[0] = payload.x; sp.payload[1] = payload.y; sp.payload[2] = payload.z;
+    a.sp_write[p] = sp;
+}
+
+// ---- TraceRay ---------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(TRAVERSE_WAVE) void k_traverse(PassArgs a, u32 inq) {
+    __shared__ int smem[LDS_STACK_DEPTH * TRAVERSE_WAVE];
+    const u32 n = a.qcount[inq];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.qcount[inq ^ 1u] = 0u; // the shade launch that follows appends into the other queue
+        a.qcount[2] = 0u;
+        atomicAdd(a.probe ? &a.stats->rays_probe : &a.stats->rays_camera, (unsigned long long) n);
+    }
+    u32 qi = blockIdx.x * TRAVERSE_WAVE + threadIdx.x;
+    TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0;
+    if (qi < n) {
+        const RayQueue& q = a.q[inq];
+        f3 o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
+        f3 d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
+        LaneStack st; st.lds = &smem[threadIdx.x]; st.sp = 0;
+        HitOut h;
+        trace_closest<LaneStack, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, h, cnt);
+        a.hits.t[qi] = h.t; a.hits.u[qi] = h.u; a.hits.v[qi] = h.v; a.hits.inst[qi] = h.inst; a.hits.tri[qi] = h.tri;
+    }
+    if (COUNT) {
+        u32 sn = wave_sum(cnt.nodes), stt = wave_sum(cnt.tris), si = wave_sum(cnt.insts);
+        if (threadIdx.x == 0) {
+            atomicAdd(&a.stats->nodes, (unsigned long long) sn);
+            atomicAdd(&a.stats->tris, (unsigned long long) stt);
+            atomicAdd(&a.stats->insts, (unsigned long long) si);
+        }
+    }
+}
+
+// ---- hit / miss shaders + the tail of the trace_path_sample loop body (raytracing.hlsl:113-119) ------------------
+__global__ __launch_bounds__(BT) void k_shade(PassArgs a, u32 inq, u32 bounce, u32 sample_index) {
+    const u32 n = a.qcount[inq];
+    u32 qi = blockIdx.x * BT + threadIdx.x;
+    bool active = qi < n;
+    bool cont = false, gather = false;
+    u32 path = 0;
+    f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
+    ShadeOut r;
+    f3 thr_prev = mk3(0, 0, 0);
+    if (active) {
+        const RayQueue& q = a.q[inq];
+        path = q.path[qi];
+        f3 o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
+        f3 d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
+        HitOut h;
+        h.t = a.hits.t[qi]; h.u = a.hits.u[qi]; h.v = a.hits.v[qi]; h.inst = a.hits.inst[qi]; h.tri = a.hits.tri[qi];
+        h.prim_global = 0;
+        u32 rng = a.ps.rng[path];
+        float payload_t = a.probe ? inf_f32() : (float) bounce; // raytracing.hlsl:102-107
+        shade_ray(a.shade, a.g, a.fudge, o, d, h, payload_t, rng, r);
+        thr_prev = mk3(a.ps.thr_x[path], a.ps.thr_y[path], a.ps.thr_z[path]);
+        f3 rad = mk3(a.ps.rad_x[path], a.ps.rad_y[path], a.ps.rad_z[path]);
+        rad = rad + r.emission * thr_prev;            // :113
+        f3 thr = thr_prev * r.reflectance;            // :114
+        bool alive = any3(r.reflectance);             // :116
+        cont = alive && bounce < a.g.bounces_per_sample;
+        gather = r.gather;
+        a.ps.rng[path] = rng;
+        a.ps.rad_x[path] = rad.x; a.ps.rad_y[path] = rad.y; a.ps.rad_z[path] = rad.z;
+        a.ps.thr_x[path] = thr.x; a.ps.thr_y[path] = thr.y; a.ps.thr_z[path] = thr.z;
+        if (bounce == 0 && h.inst < 0) a.ps.alpha[path] = 0.0f; // result.a, :122
+        if (alive) { no = o + r.t * d; nd = r.scatter; }       // :118-119
+        if (a.probe && !cont) {
+            // ray.Direction as trace_path_sample leaves it: the last traced direction after a break,
+            // the untraced scatter direction when the bounce budget ran out
+            f3 fd = alive ? r.scatter : d;
+            a.ps.fd_x[path] = fd.x; a.ps.fd_y[path] = fd.y; a.ps.fd_z[path] = fd.z;
+        }
+        if (a.capture && sample_index == 0) {
+            RtHit rec;
+            rec.instance = h.inst; rec.geometry = r.geometry; rec.primitive = r.primitive;
+            rec.t = h.inst < 0 ? inf_f32() : h.t; rec.u = h.u; rec.v = h.v; rec.rng_after = rng; rec.valid = 1u;
+            a.capture[(size_t) bounce * a.width * a.height + path] = rec;
+        }
+    }
+    u32 slot = wave_append(&a.qcount[inq ^ 1u], cont);
+    if (cont) {
+        const RayQueue& q = a.q[inq ^ 1u];
+        q.ox[slot] = no.x; q.oy[slot] = no.y; q.oz[slot] = no.z;
+        q.dx[slot] = nd.x; q.dy[slot] = nd.y; q.dz[slot] = nd.z;
+        q.path[slot] = path;
+    }
+    u32 gslot = wave_append(&a.qcount[2], gather);
+    if (gather) {
+        const GatherQueue& g = a.gq;
+        g.path[gslot] = path;
+        g.hx[gslot] = r.hit_point.x; g.hy[gslot] = r.hit_point.y; g.hz[gslot] = r.hit_point.z;
+        g.tf[gslot] = r.transmitted_fresnel;
+        g.kx[gslot] = thr_prev.x; g.ky[gslot] = thr_prev.y; g.kz[gslot] = thr_prev.z;
+        g.ti[gslot] = r.ti;
+    }
+}
+
+// ---- translucent_chit: sum of bssrdf(|p_i - hit|) * payload_i over all sample points (raytracing.hlsl:321-333) -------
+__global__ __launch_bounds__(BT) void k_gather(PassArgs a) {
+    const u32 n = a.qcount[2];
+    u32 i = blockIdx.x * BT + threadIdx.x;
+    if (i >= n) return;
+    const GatherQueue& g = a.gq;
+    u32 path = g.path[i];
+    f3 hit = mk3(g.hx[i], g.hy[i], g.hz[i]);
+    const TranslucentSlice& sl = a.shade.slices[g.ti[i]];
+    const RtSamplePoint* pts = a.sp_read + sl.offset;
+    f3 E = mk3(0.0f, 0.0f, 0.0f);
+    const float scale = a.g.translucent_bssrdf_scale;
+    if (scale != 0.0f) {
+        const float z = scale * scale;
+        for (u32 k = 0; k < sl.count; k++) {
+            const RtSamplePoint sp = pts[k];
+            f3 dp = mk3(sp.position[0], sp.position[1], sp.position[2]) - hit;
+            float radius = sqrtf(dot3(dp, dp));
+            f3 b = (a.fudge * sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, radius / scale)) / z; // :272-276
+            E = E + b * mk3(sp.payload[0], sp.payload[1], sp.payload[2]);
+        }
+    } else {
+        const float eta = a.g.translucent_refractive_index;
+        DipoleConst cr = dipole_constants(a.g.translucent_scattering[0], a.g.translucent_absorption[0], eta);
+        DipoleConst cg = dipole_constants(a.g.translucent_scattering[1], a.g.translucent_absorption[1], eta);
+        DipoleConst cb = dipole_constants(a.g.translucent_scattering[2], a.g.translucent_absorption[2], eta);
+        for (u32 k = 0; k < sl.count; k++) {
+            const RtSamplePoint sp = pts[k];
+            f3 dp = mk3(sp.position[0], sp.position[1], sp.position[2]) - hit;
+            float radius = sqrtf(dot3(dp, dp));
+            f3 b = mk3(dipole_eval(cr, radius), dipole_eval(cg, radius), dipole_eval(cb, radius));        // :278-301
+            E = E + b * mk3(sp.payload[0], sp.payload[1], sp.payload[2]);
+        }
+    }
+    E = E / (float) (a.g.translucent_accumulator_count + 1u);                                           // :332
+    f3 emission = E * g.tf[i] / (RT_TAU_F / 2.0f);                                                     // :347
+    f3 k3 = mk3(g.kx[i], g.ky[i], g.kz[i]);
+    a.ps.rad_x[path] += emission.x * k3.x; a.ps.rad_y[path] += emission.y * k3.y; a.ps.rad_z[path] += emission.z * k3.z;
+    atomicAdd(&a.stats->gather_pairs, (unsigned long long) sl.count);
+}
+
+__global__ __launch_bounds__(BT) void k_fill_capture(RtHit* capture, size_t n) {
+    size_t i = (size_t) blockIdx.x * BT + threadIdx.x;
+    if (i >= n) return;
+    RtHit r; r.instance = -1; r.geometry = -1; r.primitive = -1; r.t = 0.0f; r.u = 0.0f; r.v = 0.0f; r.rng_after = 0u; r.valid = 0u;
+    capture[i] = r;
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------
+static inline dim3 blocks(size_t n, int bt) { return dim3((unsigned) ((n + bt - 1) / bt)); }
+
+int launch_camera_raygen(hipStream_t s, const PassArgs& a, u32 sample_index) {
+    size_t threads = (size_t) a.n_local_tiles * 1024;
+    if (!threads) return RT_OK;
+    hipLaunchKernelGGL(k_camera_raygen, blocks(threads, BT), dim3(BT), 0, s, a, sample_index);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+int launch_probe_raygen(hipStream_t s, const PassArgs& a, u32 sample_index) {
+    if (!a.n_points) return RT_OK;
+    hipLaunchKernelGGL(k_probe_raygen, blocks(a.n_points, BT), dim3(BT), 0, s, a, sample_index);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+static size_t pass_paths(const PassArgs& a) { return a.probe ? (size_t) a.n_points : (size_t) a.n_local_tiles * 1024; }
+int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal) {
+    size_t n = pass_paths(a);
+    if (!n) return RT_OK;
+    if (count_traversal) hipLaunchKernelGGL(k_traverse<true>, blocks(n, TRAVERSE_WAVE), dim3(TRAVERSE_WAVE), 0, s, a, in_queue);
+    else hipLaunchKernelGGL(k_traverse<false>, blocks(n, TRAVERSE_WAVE), dim3(TRAVERSE_WAVE), 0, s, a, in_queue);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index) {
+    size_t n = pass_paths(a);
+    if (!n) return RT_OK;
+    hipLaunchKernelGGL(k_shade, blocks(n, BT), dim3(BT), 0, s, a, in_queue, bounce, sample_index);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+int launch_gather(hipStream_t s, const PassArgs& a) {
+    size_t n = pass_paths(a);
+    if (!n) return RT_OK;
+    hipLaunchKernelGGL(k_gather, blocks(n, BT), dim3(BT), 0, s, a);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+int launch_camera_resolve(hipStream_t s, const PassArgs& a) {
+    size_t threads = (size_t) a.n_local_tiles * 1024;
+    if (!threads) return RT_OK;
+    hipLaunchKernelGGL(k_camera_resolve, blocks(threads, BT), dim3(BT), 0, s, a);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+int launch_probe_resolve(hipStream_t s, const PassArgs& a) {
+    if (!a.n_points) return RT_OK;
+    hipLaunchKernelGGL(k_probe_resolve, blocks(a.n_points, BT), dim3(BT), 0, s, a);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+int launch_fill_capture(hipStream_t s, const PassArgs& a) {
+    if (!a.capture) return RT_OK;
+    size_t n = (size_t) (a.g.bounces_per_sample + 1) * a.width * a.height;
+    hipLaunchKernelGGL(k_fill_capture, blocks(n, BT), dim3(BT), 0, s, a.capture, n);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+int launch_resolve_only(hipStream_t s, const PassArgs& a) {
+    size_t n = (size_t) a.width * a.height;
+    if (!n) return RT_OK;
+    hipLaunchKernelGGL(k_resolve_only, blocks(n, BT), dim3(BT), 0, s, a);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+} // namespace rti
