@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Mrays/s (primary + secondary rays) of the HIP path tracer on MI355X.
+
+Default workload = BASELINE.json configs[1] (C2): data/bunny.obj on a floor under a luminaire, 1920x1080, 1 spp,
+bounces_per_sample = 1 ("primary + shadow" rays).  One step = one Raytracing::dispatch_rays frame
+(raytracing.cpp:652-747) with the frame_rng chain of main.cpp:443-454 advancing, so every step traces a different
+sample set into the progressive accumulator.  Inputs (scene, BVH, path buffers) are resident in HBM before timing.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): sample-set split.  Rank r renders
+frames r, r+N, ... of the chain into a private accumulator (full scene replica per GPU, no data-path collective);
+after the K steps one RCCL reduce(sum) of the RGBA32F accumulator to rank 0 closes the timed region.  Per-GPU work is
+fixed => "scaling": "weak".
+
+The JSON line also carries
+  roofline:     the dominant kernel (k_traverse): algorithmic bytes/ray x rays per launch / mean launch time (HIP events
+                on the library's stream) against the 8 TB/s HBM peak;
+  cpu_baseline: the CPU oracle (oracle/, test infrastructure) timed on this host on a bounded sample of the same
+                workload; it also supplies the per-ray node/triangle/instance counts of the bytes-per-ray model.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+class _DevBuf(object):
+    """zero-copy view of a device pointer for torch (plumbing for torch.distributed only)"""
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 3,
+                                         "strides": None}
+
+
+def build_scene(name, args):
+    from raytracer_amd import scenes
+    if name == "c2":
+        return scenes.bunny(args.width, args.height, spp=1, bounces=1), "c2: bunny.obj 1920x1080 1spp bounces=1"
+    if name == "c3":
+        return scenes.cornell(args.width, args.height, spp=args.spp or 64, bounces=4), "c3: cornell %dspp bounces=4" % (args.spp or 64)
+    if name == "c3t":
+        return scenes.cornell(args.width, args.height, spp=args.spp or 1, bounces=4, translucent_boxes=True), "c3t: cornell as shipped (dipole BSSRDF)"
+    if name == "c4":
+        return scenes.cornell_bunny(args.width, args.height, spp=args.spp or 16, bounces=4), "c4: cornell + translucent bunny skin_0 %dspp" % (args.spp or 16)
+    if name == "c5":
+        return scenes.bunny_field(args.width, args.height, spp=1, bounces=4, count=args.instances), "c5: %d instanced bunnies" % args.instances
+    raise SystemExit("unknown workload " + name)
+
+
+def cpu_baseline(scene, budget_s, threads):
+    """Oracle (CPU BVH, all threads) on whole frames of the same workload until ~budget_s of CPU time is spent."""
+    from oracle import oracle
+    from raytracer_amd import host
+    cpu = oracle.Oracle(brute_force=False, threads=threads)
+    scene.setup(cpu)
+    g = scene.globals.copy()
+    frames, t0 = 0, time.time()
+    while True:
+        g.frame_rng = host.next_frame_rng(g.frame_rng)
+        cur = cpu.get_globals()
+        g.accumulator_count = cur.accumulator_count
+        g.translucent_accumulator_count = cur.translucent_accumulator_count
+        cpu.set_globals(g)
+        cpu.dispatch_rays()
+        frames += 1
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    c = cpu.counters()
+    cpu.close()
+    rays = max(c["rays"], 1)
+    return {"value": c["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "%d full frame(s) of the same workload (%d rays, %.1f s)" % (frames, c["rays"], dt)}, \
+           {"n_node": c["nodes"] / rays, "n_tri": c["tris"] / rays, "n_inst": c["insts"] / rays}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--instances", type=int, default=52743)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from raytracer_amd import api, host, _abi
+    scene, label = build_scene(args.workload, args)
+    rt = api.Raytracer(local_rank)
+    points = scene.setup(rt)
+    acc_ptr, acc_bytes = rt.accumulator_device_ptr()
+    acc = torch.as_tensor(_DevBuf(acc_ptr, acc_bytes // 4), device=torch.device("cuda", local_rank))
+
+    g = scene.globals.copy()
+    frame_rng = g.frame_rng
+
+    def step(timed):
+        nonlocal frame_rng
+        # sample-set split: this rank owns frames rank, rank + world, ... of the frame_rng chain
+        for _ in range(world):
+            frame_rng = host.next_frame_rng(frame_rng)
+        cur = rt.get_globals()
+        g.frame_rng = frame_rng
+        g.accumulator_count = cur.accumulator_count
+        g.translucent_accumulator_count = cur.translucent_accumulator_count
+        rt.set_globals(g)
+        rt.dispatch_rays()
+
+    for _ in range(rank):  # offset this rank into the chain
+        frame_rng = host.next_frame_rng(frame_rng)
+    for _ in range(args.warmup):
+        step(False)
+    rt.sync()
+    rt.set_flags(scene.flags | _abi.RT_FLAG_TIME_KERNELS)
+    rt.reset_stats()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        rt.sync()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    rt.sync()
+    if dist is not None:
+        dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)   # RCCL over xGMI: combine the float accumulation buffers
+    fence()
+    dt = time.perf_counter() - t0
+
+    stats = rt.get_stats()
+    rays = stats["rays_camera"] + stats["rays_probe"]
+    t_rays = torch.tensor([float(rays), dt], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = t_rays.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_rays, op=dist.ReduceOp.SUM)
+        total_rays, dt_max = float(t_rays[0].item()), float(tmax[1].item())
+    else:
+        total_rays, dt_max = float(rays), dt
+
+    if rank == 0:
+        # traversal counters of this GPU's own BVH (one extra untimed frame with the counting kernel variant)
+        rt.set_flags(scene.flags | _abi.RT_FLAG_COUNT_TRAVERSAL)
+        rt.reset_stats()
+        step(False)
+        cs = rt.get_stats()
+        crays = max(cs["rays_camera"] + cs["rays_probe"], 1)
+        gpu_counts = {"n_node": cs["nodes_visited"] / crays, "n_tri": cs["tris_tested"] / crays, "n_inst": cs["instances_entered"] / crays}
+
+        cpu_line, model = None, None
+        if not args.no_cpu and world >= 1:
+            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+            cpu_line, model = cpu_baseline(scene, args.cpu_seconds, threads)
+        if model is None:
+            model = gpu_counts
+        # B_ray = 200 + 64 N_node + 48 N_tri + 64 N_inst; the traverse kernel's share of the 200 B of
+        # stream traffic is the 32 B ray it reads and the 20 B hit it writes.
+        b_trav = 52.0 + 64.0 * model["n_node"] + 48.0 * model["n_tri"] + 64.0 * model["n_inst"]
+        b_ray = 200.0 + 64.0 * model["n_node"] + 48.0 * model["n_tri"] + 64.0 * model["n_inst"]
+        launches = max(stats["traverse_launches"], 1)
+        mean_launch_ms = stats["traverse_ms"] / launches
+        rays_per_launch = rays / launches
+        achieved = (b_trav * rays_per_launch) / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s per GPU (primary+secondary) at 1080p" if (args.width, args.height) == (1920, 1080) else "Mrays/s (primary+secondary)",
+            "value": total_rays / dt_max / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": label, "width": args.width, "height": args.height, "triangles": scene.triangle_count(),
+                       "sample_points": points, "rays_per_step_per_gpu": rays / args.steps,
+                       "parallelism": "sample-set split x%d + RCCL reduce" % world if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_traverse", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_ray_traverse": b_trav, "bytes_per_ray_pipeline": b_ray,
+                         "mean_launch_ms": mean_launch_ms, "rays_per_launch": rays_per_launch,
+                         "traverse_Mrays_s": rays / (stats["traverse_ms"] * 1e-3) / 1e6 if stats["traverse_ms"] > 0 else None,
+                         "model_counts": model, "gpu_bvh_counts": gpu_counts},
+            "cpu_baseline": cpu_line,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    rt.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -447,9 +447,10 @@ void intersect_blas(const Scene& s, int inst_index, V3 o, V3 d, float tmin, floa
     int stack[128]; int sp = 0; stack[sp++] = 0;
     while (sp) {
         const BvhNode& n = b.nodes[stack[--sp]];
-        cnt.nodes++;
         float tcap = best.t < tmax ? best.t : tmax;
         if (!box_hit(n.lo, n.hi, oo, inv_d, tmin, tcap)) continue;
+        // one expanded inner node == one 64-byte two-child node fetched in the GPU layout (N_node)
+        if (n.left >= 0) cnt.nodes++;
         if (n.left < 0) {
             for (int k = n.first; k < n.first + n.count; k++) {
                 u32 i = b.bvh_tris[k];
