@@ -101,8 +101,8 @@ def instance_array(instances):
 
 class Backend(object):
     """Common wrapper over a library exporting <prefix>update_resolution, <prefix>build_blas, ... with the
-    signatures of include/rt_abi.h.  raytracer_amd.api.Raytracer (prefix rt_) is the product; the test-only CPU
-    oracle (oracle/oracle.py, prefix orc_) reuses this class so that parity tests drive both the same way."""
+    signatures of include/rt_abi.h.  raytracer_amd.api.Raytracer (prefix rt_) is the product; test code may wrap
+    another library with the same call shapes in this class so that parity tests drive both the same way."""
 
     def __init__(self, lib, prefix, handle, last_error=None):
         self.lib, self.prefix, self.h = lib, prefix, handle

@@ -1,0 +1,55 @@
+"""The C-ABI libraries load on a CPU-only machine and export every symbol their headers declare (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.mark.parametrize("header,lib", [("rt_abi.h", "raytracer_amd/librt_mi355x.so"), ("rt_host.h", "raytracer_amd/librt_host.so")])
+def test_every_declared_symbol_is_exported(header, lib):
+    names = declared_functions(header)
+    assert len(names) >= 15
+    so = ctypes.CDLL(os.path.join(ROOT, lib))
+    missing = [n for n in names if not hasattr(so, n)]
+    assert not missing, "declared in include/%s but not exported by %s: %s" % (header, lib, missing)
+
+
+def test_abi_version_and_struct_sizes():
+    from raytracer_amd import _abi
+    so = ctypes.CDLL(os.path.join(ROOT, "raytracer_amd/librt_mi355x.so"))
+    so.rt_abi_version.restype = ctypes.c_int
+    assert so.rt_abi_version() == 1
+    assert ctypes.sizeof(_abi.RtGlobals) == 156                # prelude.h:110-139
+    offs = {n: getattr(_abi.RtGlobals, n).offset for n, _ in _abi.RtGlobals._fields_}
+    assert offs["camera_to_world"] == 16 and offs["camera_aspect"] == 80 and offs["translucent_accumulator_count"] == 88
+    assert offs["translucent_emission_bounces"] == 96 and offs["translucent_scattering"] == 112
+    assert offs["translucent_absorption"] == 128 and offs["light_color"] == 144
+    assert _abi.VERTEX_DTYPE.itemsize == 24 and _abi.SAMPLE_POINT_DTYPE.itemsize == 24 and _abi.HIT_DTYPE.itemsize == 32
+    assert ctypes.sizeof(_abi.RtGeometry) == 48 and ctypes.sizeof(_abi.RtInstance) == 68
+
+
+def test_product_does_not_reference_the_oracle():
+    """the product path must never route through oracle/ (test infrastructure)"""
+    for base, _, files in os.walk(os.path.join(ROOT, "raytracer_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert not re.search(r"import\s+oracle|from\s+oracle|liboracle|\borc_[a-z]|oracle/", text), f
+
+
+def test_rt_create_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from raytracer_amd import api
+    with pytest.raises(RuntimeError):
+        api.Raytracer(0)

@@ -1,0 +1,239 @@
+"""Pins the CPU oracle (oracle/rt_oracle.cpp) against independent numpy restatements of the reference's shader
+text.  The reference ships no golden vectors, so these restatements -- written from
+random.hlsl / raytracing.hlsl directly, in float64 or exact integer arithmetic -- are the only external pin."""
+import numpy as np
+import pytest
+
+M32 = 0xFFFFFFFF
+
+
+def wang(seed):  # random.hlsl:6-15
+    seed = ((seed ^ 61) ^ (seed >> 16)) & M32
+    seed = (seed * 9) & M32
+    seed = seed ^ (seed >> 4)
+    seed = (seed * 0x27d4eb2d) & M32
+    seed = seed ^ (seed >> 15)
+    return seed
+
+
+def xorshift(s):  # random.hlsl:30-36
+    s ^= (s << 13) & M32
+    s ^= s >> 17
+    s ^= (s << 5) & M32
+    return s & M32
+
+
+def test_wang_hash_kat(oracle_mod):
+    # known answers computed by hand-expanding the five steps for seed 0: ((0^61)^0)=61, *9=549, ^(549>>4)=549^34=583,
+    # *0x27d4eb2d mod 2^32, ^(>>15)
+    assert wang(0) == oracle_mod.hash1(0) == 0xC0A9496A
+    for x in list(range(16)) + [0xFFFFFFFF, 0x12345678, 0x80000000, 61]:
+        assert oracle_mod.hash1(x) == wang(x)
+
+
+def test_hash_vectors(oracle_mod):
+    rs = np.random.RandomState(1)
+    for _ in range(50):
+        x, y, z = [int(v) for v in rs.randint(0, 2**32, 3, dtype=np.uint64)]
+        assert oracle_mod.hash2(x, y) == (wang(y) + 31 * wang(x)) & M32                       # random.hlsl:17-19
+        assert oracle_mod.hash3(x, y, z) == (wang(z) + 31 * ((wang(y) + 31 * wang(x)) & M32)) & M32  # :21-23
+
+
+def test_xorshift_and_floats(oracle_mod):
+    for seed in (1, 2, 0xDEADBEEF, 0x12345678):
+        s = seed
+        for _ in range(8):
+            r, s_after = oracle_mod.random_u32(s)
+            assert r == xorshift(s) and s_after == r
+            f01, _ = oracle_mod.random01(s)
+            bits = 0x3F800000 | (r & 0x007FFFFF)
+            expect01 = np.array([bits], dtype=np.uint32).view(np.float32)[0] - np.float32(1.0)
+            assert f01 == expect01 and 0.0 <= f01 < 1.0
+            f11, _ = oracle_mod.random11(s)
+            e11 = (np.array([expect01], dtype=np.float32).view(np.uint32)[0] | (r & 0x80000000))
+            assert f11 == np.array([e11], dtype=np.uint32).view(np.float32)[0]
+            s = r
+    # seed 0 is a fixed point of xorshift: every draw is 0
+    assert oracle_mod.random_u32(0) == (0, 0)
+
+
+def test_sincos_accuracy(oracle_mod):
+    phis = np.concatenate([np.linspace(0, 2 * np.pi, 4001), [0.0, np.pi / 4, np.pi / 2, np.pi, 1.5 * np.pi, 6.2831855]]).astype(np.float32)
+    err = 0.0
+    for p in phis:
+        s, c = oracle_mod.sincos(float(p))
+        err = max(err, abs(float(s) - np.sin(np.float64(p))), abs(float(c) - np.cos(np.float64(p))))
+    assert err < 2.5e-7
+
+
+def test_samplers(oracle_mod):
+    n = np.array([0.0, 0.6, 0.8], dtype=np.float32)
+    seed = 12345
+    for _ in range(200):
+        v, seed2 = oracle_mod.random_on_sphere(seed)
+        assert abs(float(np.dot(v.astype(np.float64), v.astype(np.float64))) - 1.0) < 1e-6
+        # restatement of random.hlsl:70-75 in float64 from the same integer stream
+        r1 = xorshift(seed); r2 = xorshift(r1)
+        assert seed2 == r2
+        phi = ((np.array([0x3F800000 | (r1 & 0x7FFFFF)], dtype=np.uint32).view(np.float32)[0]) - np.float32(1)) * np.float32(6.2831855)
+        ct = np.array([0x3F800000 | (r2 & 0x7FFFFF)], dtype=np.uint32).view(np.float32)[0] - np.float32(1)
+        ct = -ct if (r2 & 0x80000000) else ct
+        st = np.sqrt(1.0 - float(ct) ** 2)
+        ref = np.array([st * np.cos(float(phi)), st * np.sin(float(phi)), float(ct)])
+        assert np.allclose(v, ref, atol=5e-7)
+        h, _ = oracle_mod.random_on_hemisphere(seed, n)
+        assert np.dot(h, n) >= -1e-6                                   # reflected into the normal's side
+        d = 2.0 * np.dot(n.astype(np.float64), ref)
+        assert np.allclose(h, ref - min(0.0, d) * n, atol=1e-6)        # random.hlsl:85-88
+        seed = seed2
+
+
+def test_schlick(oracle_mod):
+    for n in (1.0, 1.33, 1.75, 5.0):
+        for c in np.linspace(-0.2, 1.0, 13):
+            r0 = ((n - 1) / (n + 1)) ** 2
+            ref = r0 + (1 - r0) * (1 - c) ** 5                          # raytracing.hlsl:211-222
+            assert abs(float(oracle_mod.schlick(n, float(c))) - ref) < 1e-5 * max(1.0, abs(ref))
+
+
+def _moller_trumbore(o, d, p0, p1, p2):
+    e1, e2 = p1 - p0, p2 - p0
+    pv = np.cross(d, e2); det = np.dot(e1, pv)
+    if abs(det) < 1e-300:
+        return None
+    tv = o - p0; u = np.dot(tv, pv) / det
+    qv = np.cross(tv, e1); v = np.dot(d, qv) / det
+    t = np.dot(e2, qv) / det
+    return t, u, v
+
+
+def test_triangle_test_against_float64(oracle_mod):
+    rs = np.random.RandomState(7)
+    n_hit = 0
+    for _ in range(3000):
+        p = rs.uniform(-1, 1, (3, 3)).astype(np.float32)
+        o = rs.uniform(-3, 3, 3).astype(np.float32)
+        target = (p[0] * 0.3 + p[1] * 0.3 + p[2] * 0.4) + rs.normal(0, 0.4, 3)
+        d = (target - o).astype(np.float32)
+        hit, tuv = oracle_mod.intersect_triangle(o, d, p[0], p[1], p[2])
+        ref = _moller_trumbore(*[x.astype(np.float64) for x in (o, d, p[0], p[1], p[2])])
+        front = np.dot(np.cross(p[1].astype(np.float64) - p[0], p[2].astype(np.float64) - p[0]), d) < 0
+        inside = ref is not None and ref[1] > 1e-4 and ref[2] > 1e-4 and ref[1] + ref[2] < 1 - 1e-4
+        outside = ref is None or ref[1] < -1e-4 or ref[2] < -1e-4 or ref[1] + ref[2] > 1 + 1e-4
+        if inside and front:
+            assert hit
+            assert np.allclose(tuv, ref, rtol=2e-4, atol=2e-5)
+            n_hit += 1
+        if outside or (inside and not front):
+            assert not hit, "back faces and misses must be rejected"
+        # the reversed winding sees the other face
+        hit_rev, _ = oracle_mod.intersect_triangle(o, d, p[0], p[2], p[1])
+        if inside:
+            assert hit_rev == (not front)
+    assert n_hit > 300
+
+
+def test_triangle_test_is_watertight_on_shared_edges(oracle_mod):
+    """rays through points of the diagonal shared by the two triangles of a quad hit at least one of them"""
+    q = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], dtype=np.float32)
+    rs = np.random.RandomState(3)
+    for _ in range(2000):
+        a = np.float32(rs.uniform(0, 1))
+        on_edge = q[0] + a * (q[2] - q[0])
+        o = np.array([rs.uniform(-2, 2), rs.uniform(-2, 2), rs.uniform(0.5, 3)], dtype=np.float32)
+        d = (on_edge - o).astype(np.float32)
+        h1, _ = oracle_mod.intersect_triangle(o, d, q[0], q[1], q[2])
+        h2, _ = oracle_mod.intersect_triangle(o, d, q[0], q[2], q[3])
+        assert h1 or h2
+
+
+def test_invert_affine(oracle_mod):
+    rs = np.random.RandomState(5)
+    for _ in range(20):
+        ang = rs.uniform(0, 6.28); s = rs.uniform(0.1, 4)
+        m = np.eye(4)
+        m[:3, :3] = s * np.array([[np.cos(ang), np.sin(ang), 0], [-np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+        m[3, :3] = rs.uniform(-5, 5, 3)
+        m32 = m.astype(np.float32)
+        inv = oracle_mod.invert_affine(m32)
+        ref = np.linalg.inv(m32.astype(np.float64))
+        assert np.allclose(inv[:3], ref[:3, :3], rtol=1e-6, atol=1e-7)
+        assert np.allclose(inv[3], ref[3, :3], rtol=1e-6, atol=1e-6)
+
+
+def test_bssrdf_dipole_and_table(oracle_mod):
+    from raytracer_amd import host, scenes
+    o = oracle_mod.Oracle()
+    s = scenes.cornell_bunny(32, 18)
+    s.setup(o)
+    g = s.globals
+    # raytracing.hlsl:278-301 in float64
+    ss, sa, eta = 15.0, 0.1, 1.75
+    g2 = g.copy(); g2.translucent_bssrdf_scale = 0.0
+    for k in range(3):
+        g2.translucent_scattering[k] = ss; g2.translucent_absorption[k] = sa
+    o.set_globals(g2)
+    for r in (0.0, 0.001, 0.01, 0.05, 0.1, 0.3, 1.0, 3.0):
+        st = ss + sa; mfp = 1 / st; alb = ss / st; str_ = np.sqrt(3 * ss * sa)
+        fdr = -1.440 / eta**2 + 0.710 / eta + 0.668 + 0.0636 * eta
+        zr = mfp; dr = r + zr; cr = zr * (str_ + 1 / dr)
+        zv = mfp * (1 + 1.25 * (1 + fdr) / (1 - fdr)); dv = r + zv; cv = zv * (str_ + 1 / dv)
+        ref = max(0.0, alb / (2 * 2 * np.pi) * (cr * np.exp(-str_ * dr) / dr**2 + cv * np.exp(-str_ * dv) / dv**2))
+        got = o.bssrdf_dipole(r)
+        assert np.allclose(got, ref, rtol=2e-5), (r, got, ref)
+    # tabulated: linear filter at u*2048 - 0.5 over the zero-padded table, border 0 (raytracing.hlsl:272-276)
+    o.set_globals(g)
+    tab = np.zeros((2048, 3)); tab[:2000] = host.load_skin_table(0).T
+    scale, fudge = g.translucent_bssrdf_scale, g.translucent_bssrdf_fudge
+    for r in (0.0, 1e-4, 0.003, 0.02, 0.1, 0.39, 0.3999, 0.41, 2.0):
+        x = (r / scale) * 2048 - 0.5
+        i0 = int(np.floor(x)); f = x - i0
+        a = tab[i0] if 0 <= i0 < 2048 else np.zeros(3)
+        b = tab[i0 + 1] if 0 <= i0 + 1 < 2048 else np.zeros(3)
+        ref = fudge * (a + f * (b - a)) / scale**2
+        assert np.allclose(o.bssrdf_tabulated(r), ref, rtol=1e-4, atol=1e-6), r
+    o.close()
+
+
+def test_phase_sequence_is_a_seeded_permutation(oracle_mod):
+    a = oracle_mod.phase_sequence(2, 24)
+    assert sorted(a) == list(range(24)) and a != list(range(24))
+    assert a == oracle_mod.phase_sequence(2, 24) and a != oracle_mod.phase_sequence(3, 24)
+    assert sorted(oracle_mod.phase_sequence(2, 27)) == list(range(27))
+
+
+def test_load_3x16bit_indices_restatement():
+    """prelude.h:195-218 reads an aligned dword pair and picks the lower or upper three halves; for a tightly packed
+    16-bit index buffer that equals plain indexing, which is what both the oracle and the HIP path do."""
+    idx = np.arange(100, 100 + 30, dtype=np.uint16)
+    raw = idx.tobytes() + b"\0\0\0\0"
+    for prim in range(10):
+        byte = prim * 6; aligned = byte & ~3
+        d0, d1 = np.frombuffer(raw[aligned:aligned + 8], dtype=np.uint32)
+        if byte == aligned:
+            got = (d0 & 0xFFFF, d0 >> 16, d1 & 0xFFFF)
+        else:
+            got = (d0 >> 16, d1 & 0xFFFF, d1 >> 16)
+        assert tuple(int(x) for x in got) == tuple(int(x) for x in idx[3 * prim:3 * prim + 3])
+
+
+def test_oracle_bvh_matches_brute_force(oracle_mod):
+    from raytracer_amd import scenes, _abi
+    for scene in (scenes.bunny(96, 54, spp=1, bounces=2), scenes.cornell(64, 36, spp=2, bounces=3)):
+        a, b = oracle_mod.Oracle(brute_force=True, threads=4), oracle_mod.Oracle(brute_force=False, threads=4)
+        scene.setup(a, _abi.RT_FLAG_CAPTURE_HITS); scene.setup(b, _abi.RT_FLAG_CAPTURE_HITS)
+        a.dispatch_rays(); b.dispatch_rays()
+        for bounce in range(scene.globals.bounces_per_sample + 1):
+            assert a.read_hit_records(bounce).tobytes() == b.read_hit_records(bounce).tobytes()
+        assert a.read_accumulator().tobytes() == b.read_accumulator().tobytes()
+        a.close(); b.close()
+
+
+def test_oracle_threads_do_not_change_results(oracle_mod):
+    from raytracer_amd import scenes
+    scene = scenes.cornell_bunny(48, 27, spp=2, bounces=2, sample_radius=0.06)
+    a, b = oracle_mod.Oracle(threads=1), oracle_mod.Oracle(threads=8)
+    assert scene.setup(a) == scene.setup(b) > 0
+    a.dispatch_rays(); b.dispatch_rays()
+    assert a.read_accumulator().tobytes() == b.read_accumulator().tobytes()
+    a.close(); b.close()
