@@ -32,7 +32,7 @@ def main():
             v, s = oracle.random11(s); d11.append(int(np.float32(v).view(np.uint32)))
         kat["draws"][str(seed)] = {"random01_bits": d01, "random11_bits": d11}
     kat["schlick_bits"] = {"%g,%g" % (n, c): int(oracle.schlick(n, c).view(np.uint32)) for n in (1.33, 1.75) for c in (0.0, 0.25, 0.5, 1.0)}
-    kat["sincos_bits"] = {"%g" % p: [int(x.view(np.uint32)) for x in oracle.sincos(p)] for p in (0.0, 0.5, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 6.2831855)}
+    kat["sincos_bits"] = {repr(p): [int(x.view(np.uint32)) for x in oracle.sincos(p)] for p in (0.0, 0.5, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 6.25)}
     o = oracle.Oracle()
     s4 = scenes.cornell_bunny(32, 18)
     s4.setup(o)
