@@ -77,7 +77,7 @@ struct rt_ctx {
     // path buffers
     u32 n_paths = 0; float* d_arena = nullptr;
     RayQueue q[2]; HitBuf hits; PathState ps; GatherQueue gq;
-    u32* d_qcount = nullptr; DeviceStats* d_stats = nullptr;
+    u32* d_seg_count = nullptr; u32 n_segments_cap = 0; DeviceStats* d_stats = nullptr;
     // BSSRDF tables
     float* d_table[2] = { nullptr, nullptr }; int table_texels[2] = { 0, 0 }; int profile = 0;
     // stats
@@ -104,10 +104,15 @@ void invert_affine(const float* m, float* inv) {
 }
 
 int ensure_path_buffers(rt_ctx* c) {
-    u32 need = std::max(c->width * c->height, c->n_points);
-    if (need == 0) need = 64;
+    u32 tiles = ((c->width + 31) / 32) * ((c->height + 31) / 32);
+    u32 segs = std::max(tiles, (c->n_points + 1023) / 1024);
+    if (segs == 0) segs = 1;
+    u32 need = segs * 1024; // queue slots; path-state arrays are indexed by pixel / point id < need
     if (need <= c->n_paths) return RT_OK;
-    dev_free(c->d_arena);
+    dev_free(c->d_arena); dev_free(c->d_seg_count);
+    RT_HIP(hipMalloc(&c->d_seg_count, 3 * sizeof(u32) * (size_t) segs));
+    RT_HIP(hipMemset(c->d_seg_count, 0, 3 * sizeof(u32) * (size_t) segs));
+    c->n_segments_cap = segs;
     const int n_arrays = 14 /* 2 queues x (6 + path) */ + 5 /* hits */ + 15 /* path state */ + 9 /* gather */;
     size_t stride = ((size_t) need + 63) & ~(size_t) 63;
     RT_HIP(hipMalloc(&c->d_arena, stride * 4 * n_arrays));
@@ -152,7 +157,11 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.shade.insts = c->d_inst_shade; a.shade.slot_to_ti = c->d_slot_to_ti; a.shade.slot_count = c->slot_count;
     a.shade.slices = c->d_slices;
     a.q[0] = c->q[0]; a.q[1] = c->q[1]; a.hits = c->hits; a.ps = c->ps; a.gq = c->gq;
-    a.qcount = c->d_qcount; a.stats = c->d_stats;
+    a.n_segments = probe ? (c->n_points + 1023) / 1024 : a.n_local_tiles;
+    a.gather_enabled = (!probe && c->n_points > 0 && a.fudge != 0.0f) ? 1u : 0u;
+    a.seg_count[0] = c->d_seg_count; a.seg_count[1] = c->d_seg_count + c->n_segments_cap;
+    a.gseg_count = c->d_seg_count + 2 * (size_t) c->n_segments_cap;
+    a.stats = c->d_stats;
     a.capture = nullptr;
     a.accumulator = c->d_accumulator; a.render_target = c->d_render_target;
     a.sp_read = c->d_sp_read; a.sp_write = c->d_sp_write; a.sp_normal = c->d_sp_normal; a.sp_slice = c->d_sp_slice;
@@ -199,9 +208,8 @@ int run_pass(rt_ctx* c, bool probe) {
         a.capture = c->d_capture;
         int rc = launch_fill_capture(c->stream, a); if (rc) return rc;
     }
-    bool gather = !probe && c->n_points > 0 && a.fudge != 0.0f;
+    bool gather = a.gather_enabled != 0;
     for (u32 s = 0; s < c->g.samples_per_pixel; s++) {
-        RT_HIP(hipMemsetAsync(c->d_qcount, 0, 4 * sizeof(u32), c->stream));
         int rc = probe ? launch_probe_raygen(c->stream, a, s) : launch_camera_raygen(c->stream, a, s);
         if (rc) return rc;
         for (u32 b = 0; b <= c->g.bounces_per_sample; b++) {
@@ -251,9 +259,7 @@ int rt_create(const int* devices, int n, rt_ctx** out) {
     c->device = devices[0];
     RT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    RT_HIP(hipMalloc(&c->d_qcount, 4 * sizeof(u32)));
     RT_HIP(hipMalloc(&c->d_stats, sizeof(DeviceStats)));
-    RT_HIP(hipMemset(c->d_qcount, 0, 4 * sizeof(u32)));
     RT_HIP(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
     *out = c;
     return RT_OK;
@@ -272,7 +278,7 @@ void rt_destroy(rt_ctx* c) {
     free_sample_points(c);
     dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
     dev_free(c->d_accumulator); dev_free(c->d_render_target); dev_free(c->d_capture); dev_free(c->d_arena);
-    dev_free(c->d_qcount); dev_free(c->d_stats); dev_free(c->d_table[0]); dev_free(c->d_table[1]);
+    dev_free(c->d_seg_count); dev_free(c->d_stats); dev_free(c->d_table[0]); dev_free(c->d_table[1]);
     lbvh_workspace_free(c->lbvh);
     if (c->own_stream) (void) hipStreamDestroy(c->own_stream);
     delete c;

@@ -86,7 +86,10 @@ struct PassArgs {
     HitBuf hits;
     PathState ps;
     GatherQueue gq;
-    u32* qcount;                 // [0],[1] ray queue sizes, [2] gather queue size
+    u32 n_segments;              // queue segments of 1024 rays in this pass (tiles, or ceil(n_points / 1024))
+    u32 gather_enabled;
+    u32* seg_count[2];           // rays per segment of the two ping-pong queues
+    u32* gseg_count;             // gather items per segment
     DeviceStats* stats;
     RtHit* capture;              // [(bounces+1) * width*height] or null
     float* accumulator;          // RGBA32F
