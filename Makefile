@@ -11,7 +11,7 @@ HIP_SRCS := $(CSRC)/rt_api.hip $(CSRC)/rt_kernels.hip $(CSRC)/rt_bvh.hip $(CSRC)
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
 HIP_HDRS := $(wildcard $(CSRC)/*.h) include/rt_abi.h
 
-all: raytracer_amd/librt_mi355x.so raytracer_amd/librt_host.so oracle/liboracle.so
+all: raytracer_amd/librt_mi355x.so raytracer_amd/librt_host.so oracle/liboracle.so raytracer_amd/rt_render
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -22,10 +22,14 @@ raytracer_amd/librt_mi355x.so: $(HIP_OBJS)
 raytracer_amd/librt_host.so: raytracer_amd/host/rt_host.cpp include/rt_host.h include/rt_abi.h
 	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -shared -o $@ raytracer_amd/host/rt_host.cpp
 
+# headless frame loop (main.cpp replacement) on top of the two libraries
+raytracer_amd/rt_render: raytracer_amd/host/rt_render.cpp raytracer_amd/host/raytracing.hpp raytracer_amd/librt_mi355x.so raytracer_amd/librt_host.so
+	$(CXX) -O2 -std=c++17 -Wall -o $@ raytracer_amd/host/rt_render.cpp -Lraytracer_amd -lrt_mi355x -lrt_host '-Wl,-rpath,$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+
 oracle/liboracle.so: oracle/rt_oracle.cpp include/rt_abi.h
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(HIP_OBJS) raytracer_amd/librt_mi355x.so raytracer_amd/librt_host.so oracle/liboracle.so
+	rm -f $(HIP_OBJS) raytracer_amd/rt_render raytracer_amd/librt_mi355x.so raytracer_amd/librt_host.so oracle/liboracle.so
 
 .PHONY: all clean

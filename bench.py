@@ -112,24 +112,17 @@ def main():
     points = scene.setup(rt)
     acc_ptr, acc_bytes = rt.accumulator_device_ptr()
     acc = torch.as_tensor(_DevBuf(acc_ptr, acc_bytes // 4), device=torch.device("cuda", local_rank))
+    del acc_ptr
 
-    g = scene.globals.copy()
-    frame_rng = g.frame_rng
+    from raytracer_amd import distributed
+    chain = distributed.FrameChain(scene.globals.frame_rng)
+    step_index = [0]
 
     def step(timed):
-        nonlocal frame_rng
         # sample-set split: this rank owns frames rank, rank + world, ... of the frame_rng chain
-        for _ in range(world):
-            frame_rng = host.next_frame_rng(frame_rng)
-        cur = rt.get_globals()
-        g.frame_rng = frame_rng
-        g.accumulator_count = cur.accumulator_count
-        g.translucent_accumulator_count = cur.translucent_accumulator_count
-        rt.set_globals(g)
-        rt.dispatch_rays()
+        distributed.render_frame(rt, scene.globals, step_index[0] * world + rank, chain)
+        step_index[0] += 1
 
-    for _ in range(rank):  # offset this rank into the chain
-        frame_rng = host.next_frame_rng(frame_rng)
     for _ in range(args.warmup):
         step(False)
     rt.sync()

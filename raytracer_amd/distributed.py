@@ -1,0 +1,77 @@
+"""Multi-GPU sharding of the path: one process per GPU, torch.distributed (RCCL on GPUs, gloo on CPU
+for tests) for the single exchange step.  The reference is single-GPU; these are the two partitions its data flow
+allows without changing any pixel's sample stream:
+
+  tile split    (C4)  rank r renders the 32x32 tiles t with t % world == r; a pixel's RNG stream depends only on
+                      (px, py, frame seed) (raytracing.hlsl:130), so each pixel is bit-identical to the 1-GPU render.
+                      Other ranks' pixels stay zero in the accumulator, so sum(all ranks) reproduces it exactly.
+                      The probe pass (translucent_rgen) is replicated on every rank: it is ~N_points*spp paths against
+                      W*H*spp camera paths, and replication keeps sample-point payloads bit-identical without an exchange.
+  sample split  (C5)  rank r renders frames r, r+world, ... of the frame_rng chain (main.cpp:443-454) into its own
+                      accumulator; one reduce(sum) of the RGBA32F buffer at the end.  Equal to the sequential sum up to
+                      float re-association.
+"""
+import numpy as np
+
+from . import host
+
+
+def frame_seed(seed0, frame):
+    """frame_rng used by frame `frame` (0-based): the main loop hashes before every dispatch (main.cpp:443-454)."""
+    s = seed0
+    for _ in range(frame + 1):
+        s = host.next_frame_rng(s)
+    return s
+
+
+class FrameChain(object):
+    """incremental frame_seed for monotonically increasing frame indices"""
+
+    def __init__(self, seed0):
+        self.seed, self.frame = seed0, -1
+
+    def seed_for(self, frame):
+        assert frame > self.frame
+        while self.frame < frame:
+            self.seed = host.next_frame_rng(self.seed)
+            self.frame += 1
+        return self.seed
+
+
+def render_frame(backend, base_globals, frame, seed0):
+    """Dispatches global frame `frame`: seeds as the sequential loop would and adds into this backend's accumulator
+    (which must still be zero where no earlier frame of this backend has written)."""
+    g = base_globals.copy()
+    cur = backend.get_globals()
+    g.frame_rng = seed0.seed_for(frame) if isinstance(seed0, FrameChain) else frame_seed(seed0, frame)
+    g.accumulator_count = frame                       # frame 0 seeds with z = 0; later frames add
+    g.translucent_accumulator_count = cur.translucent_accumulator_count
+    backend.set_globals(g)
+    backend.dispatch_rays()
+
+
+def sample_split_frames(rank, world, total_frames):
+    return list(range(rank, total_frames, world))
+
+
+def device_accumulator(rt, device):
+    """zero-copy torch view of the product's accumulator (plumbing for the collective only)"""
+    import torch
+
+    class _Buf(object):
+        pass
+    ptr, nbytes = rt.accumulator_device_ptr()
+    b = _Buf()
+    b.__cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 3, "strides": None}
+    return torch.as_tensor(b, device=device)
+
+
+def reduce_accumulator(tensor, dist, dst=0, all_ranks=False):
+    """the one exchange step: sum of the float accumulation buffers (RCCL over xGMI / gloo)"""
+    if dist is None or dist.get_world_size() == 1:
+        return tensor
+    if all_ranks:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+    else:
+        dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
+    return tensor

@@ -60,3 +60,27 @@ def test_c3_cornell_small(oracle_mod):
 
 def test_odd_resolution_not_multiple_of_tile(oracle_mod):
     _check_scene(scenes.cornell(77, 45, spp=1, bounces=2), oracle_mod)
+
+
+def test_tile_split_sums_to_the_full_image(oracle_mod):
+    """two tile-split contexts (ranks 0 and 1 of 2) on one GPU: accumulators are disjoint and their sum is the
+    single-context image bit for bit"""
+    from raytracer_amd import api, distributed
+    scene = scenes.cornell_bunny(100, 70, spp=2, bounces=2, sample_radius=0.06)
+    full = api.Raytracer(0); scene.setup(full)
+    parts = []
+    for r in range(2):
+        rt = api.Raytracer(0); scene.setup(rt); rt.set_tile_split(r, 2); parts.append(rt)
+    for f in range(2):
+        for rt in [full] + parts:
+            distributed.render_frame(rt, scene.globals, f, 99)
+    a, b, whole = parts[0].read_accumulator(), parts[1].read_accumulator(), full.read_accumulator()
+    assert not np.any((a != 0) & (b != 0))
+    assert np.array_equal((a + b).view(np.uint32), whole.view(np.uint32))
+    cpu = oracle_mod.Oracle(brute_force=True, threads=8); scene.setup(cpu)
+    for f in range(2):
+        distributed.render_frame(cpu, scene.globals, f, 99)
+    pu.compare_images(whole, cpu.read_accumulator())
+    for rt in [full] + parts:
+        rt.close()
+    cpu.close()
