@@ -54,7 +54,7 @@ template <typename T> void dev_free(T*& p) { if (p) { (void) hipFree(p); p = nul
 struct rt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    LbvhWorkspace lbvh;
+    LbvhWorkspace lbvh; PlocWorkspace ploc; int bvh_builder = 1; // RT_BVH_BUILDER: 0 LBVH, 1 PLOC
     std::vector<Blas> blas;
     std::vector<TranslucentMesh> translucent_meshes;
     std::vector<float> translucent_mean_area; // g_translucent_properties
@@ -74,6 +74,7 @@ struct rt_ctx {
     float* d_accumulator = nullptr; uint8_t* d_render_target = nullptr;
     RtHit* d_capture = nullptr; size_t capture_records = 0; u32 capture_bounces = 0;
     u32 tile_rank = 0, tile_world = 1;
+    int traverse_variant = 1; // RT_TRAVERSE_VARIANT: kernel A/B switch (tuning aid)
     // path buffers
     u32 n_paths = 0; float* d_arena = nullptr;
     RayQueue q[2]; HitBuf hits; PathState ps; GatherQueue gq;
@@ -176,7 +177,7 @@ int timed_traverse(rt_ctx* c, const PassArgs& a, u32 inq) {
         RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
         RT_HIP(hipEventRecord(e0, c->stream));
     }
-    int rc = launch_traverse(c->stream, a, inq, (c->flags & RT_FLAG_COUNT_TRAVERSAL) != 0);
+    int rc = launch_traverse(c->stream, a, inq, (c->flags & RT_FLAG_COUNT_TRAVERSAL) != 0, c->traverse_variant);
     if (timing) { RT_HIP(hipEventRecord(e1, c->stream)); c->timed.emplace_back(e0, e1); }
     c->traverse_launches++;
     return rc;
@@ -257,6 +258,8 @@ int rt_create(const int* devices, int n, rt_ctx** out) {
     RT_HIP(hipSetDevice(devices[0]));
     rt_ctx* c = new rt_ctx();
     c->device = devices[0];
+    if (const char* v = getenv("RT_TRAVERSE_VARIANT")) c->traverse_variant = atoi(v);
+    if (const char* v = getenv("RT_BVH_BUILDER")) c->bvh_builder = atoi(v);
     RT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     RT_HIP(hipMalloc(&c->d_stats, sizeof(DeviceStats)));
@@ -279,7 +282,7 @@ void rt_destroy(rt_ctx* c) {
     dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
     dev_free(c->d_accumulator); dev_free(c->d_render_target); dev_free(c->d_capture); dev_free(c->d_arena);
     dev_free(c->d_seg_count); dev_free(c->d_stats); dev_free(c->d_table[0]); dev_free(c->d_table[1]);
-    lbvh_workspace_free(c->lbvh);
+    lbvh_workspace_free(c->lbvh); ploc_workspace_free(c->ploc);
     if (c->own_stream) (void) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -396,7 +399,7 @@ int rt_build_blas(rt_ctx* c, const RtGeometry* geometries, int n, rt_blas* out) 
     int rc = lbvh_workspace_reserve(c->lbvh, b.n_tris); if (rc) return rc;
     RT_HIP(hipEventRecord(e0, c->stream));
     rc = lbvh_triangle_boxes(c->stream, c->lbvh, b.d_verts, b.d_indices, b.n_tris); if (rc) return rc;
-    rc = lbvh_build(c->stream, c->lbvh, b.n_tris, RT_LEAF_MAX_TRIS, false, b.d_nodes, b.d_perm); if (rc) return rc;
+    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, c->bvh_builder, b.n_tris, RT_LEAF_MAX_TRIS, false, b.d_nodes, b.d_perm); if (rc) return rc;
     rc = lbvh_write_trirecs(c->stream, b.d_perm, b.d_verts, b.d_indices, b.d_tri_geometry, b.d_geoms, b.n_tris, b.d_tris); if (rc) return rc;
     RT_HIP(hipEventRecord(e1, c->stream));
     BvhNode root;
@@ -459,7 +462,7 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
     RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
     RT_HIP(hipEventRecord(e0, c->stream));
     rc = lbvh_instance_boxes(c->stream, c->lbvh, c->d_inst_shade, c->d_inst_rec, (u32) n); if (rc) return rc;
-    rc = lbvh_build(c->stream, c->lbvh, (u32) n, 1, true, c->d_tlas_nodes, c->d_tlas_perm); if (rc) return rc;
+    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, c->bvh_builder, (u32) n, 1, true, c->d_tlas_nodes, c->d_tlas_perm); if (rc) return rc;
     RT_HIP(hipEventRecord(e1, c->stream));
     BvhNode root;
     RT_HIP(hipMemcpyAsync(&root, c->d_tlas_nodes, sizeof root, hipMemcpyDeviceToHost, c->stream));

@@ -95,8 +95,19 @@ __global__ void k_hierarchy(const u32* __restrict__ keys, int n, BuildNode* __re
 RT_DEV float load_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // bottom-up: the second thread to arrive at a node merges its children's boxes and continues upwards
+RT_DEV float half_area(const Aabb& b) {
+    float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
+    return ex * ey + ey * ez + ez * ex;
+}
+// surface-area-heuristic constants: one two-child node fetch+test vs one triangle fetch+test on gfx950
+#define RT_SAH_NODE 1.0f
+#define RT_SAH_TRI  1.3f
+
+// cost[] holds the un-normalised SAH cost of the best cut of each subtree; collapsed[] marks subtrees that are
+// cheaper as one leaf of <= leaf_max primitives
 __global__ void k_refit(const Aabb* __restrict__ boxes, const u32* __restrict__ perm, int n, const BuildNode* __restrict__ bn,
-                        const int* __restrict__ leaf_parent, Aabb* node_boxes, int* depth, u32* flags) {
+                        const int* __restrict__ leaf_parent, Aabb* node_boxes, int* depth, u32* flags, float* cost,
+                        u32* collapsed, int leaf_max) {
     int leaf = blockIdx.x * blockDim.x + threadIdx.x;
     if (leaf >= n) return;
     int node = leaf_parent[leaf];
@@ -105,14 +116,16 @@ __global__ void k_refit(const Aabb* __restrict__ boxes, const u32* __restrict__ 
         u32 old = atomicAdd(&flags[node], 1u);
         if (old == 0) return;
         __threadfence(); // acquire the sibling's writes
-        Aabb b; int dep = 0;
+        Aabb b; int dep = 0; float child_cost = 0.0f;
         for (int k = 0; k < 3; k++) { b.lo[k] = 3.4e38f; b.hi[k] = -3.4e38f; }
         int child[2] = { bn[node].left, bn[node].right };
         for (int c = 0; c < 2; c++) {
             if (child[c] < 0) {
                 const Aabb& cb = boxes[perm[~child[c]]];
                 for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], cb.lo[k]); b.hi[k] = fmaxf(b.hi[k], cb.hi[k]); }
+                child_cost += RT_SAH_TRI * half_area(cb);
             } else {
+                child_cost += load_agent(&cost[child[c]]);
                 const Aabb* cb = &node_boxes[child[c]];
                 for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], load_agent(&cb->lo[k])); b.hi[k] = fmaxf(b.hi[k], load_agent(&cb->hi[k])); }
                 int cd = __hip_atomic_load(&depth[child[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -121,6 +134,12 @@ __global__ void k_refit(const Aabb* __restrict__ boxes, const u32* __restrict__ 
         }
         node_boxes[node] = b;
         depth[node] = dep + 1;
+        int size = bn[node].last - bn[node].first + 1;
+        float a = half_area(b);
+        float split_cost = RT_SAH_NODE * a + child_cost, leaf_cost = RT_SAH_TRI * (float) size * a;
+        bool col = size <= leaf_max && leaf_cost <= split_cost;
+        collapsed[node] = col ? 1u : 0u;
+        cost[node] = col ? leaf_cost : split_cost;
         node = bn[node].parent;
     }
 }
@@ -131,15 +150,15 @@ RT_DEV Aabb child_box(int child, const Aabb* boxes, const u32* perm, const Aabb*
 
 __global__ void k_emit(const Aabb* __restrict__ boxes, const u32* __restrict__ perm, int n, const BuildNode* __restrict__ bn,
                        const Aabb* __restrict__ node_boxes, const int* __restrict__ depth, const Aabb* __restrict__ scene,
-                       int leaf_max, int tlas, BvhNode* __restrict__ out) {
+                       const u32* __restrict__ collapsed, int tlas, BvhNode* __restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     BvhNode nd;
     Aabb b0 = child_box(bn[i].left, boxes, perm, node_boxes), b1 = child_box(bn[i].right, boxes, perm, node_boxes);
     set_box(nd.lo0, nd.hi0, b0);
     set_box(nd.lo1, nd.hi1, b1);
-    nd.c0 = lbvh_child_link(bn[i].left, bn, perm, leaf_max, tlas != 0);
-    nd.c1 = lbvh_child_link(bn[i].right, bn, perm, leaf_max, tlas != 0);
+    nd.c0 = lbvh_child_link(bn[i].left, bn, perm, collapsed, tlas != 0);
+    nd.c1 = lbvh_child_link(bn[i].right, bn, perm, collapsed, tlas != 0);
     nd.bound = 0.0f; nd.depth = 0;
     if (i == 0) {
         float m = 0.0f;
@@ -194,6 +213,8 @@ int lbvh_workspace_reserve(LbvhWorkspace& w, u32 n) {
     RT_HIP(hipMalloc(&w.leaf_parent, 4 * (size_t) cap));
     RT_HIP(hipMalloc(&w.flags, 4 * (size_t) cap));
     RT_HIP(hipMalloc(&w.depth, 4 * (size_t) cap));
+    RT_HIP(hipMalloc(&w.cost, 4 * (size_t) cap));
+    RT_HIP(hipMalloc(&w.collapsed, 4 * (size_t) cap));
     RT_HIP(hipMalloc(&w.sort_scratch, sort_scratch_bytes(cap)));
     w.capacity = cap;
     return RT_OK;
@@ -201,7 +222,7 @@ int lbvh_workspace_reserve(LbvhWorkspace& w, u32 n) {
 
 void lbvh_workspace_free(LbvhWorkspace& w) {
     void* ptrs[] = { w.boxes, w.node_boxes, w.scene_box, w.keys, w.vals, w.keys_tmp, w.vals_tmp, w.build_nodes,
-                     w.leaf_parent, w.flags, w.depth, w.sort_scratch };
+                     w.leaf_parent, w.flags, w.depth, w.cost, w.collapsed, w.sort_scratch };
     for (void* p : ptrs) if (p) (void) hipFree(p);
     w = LbvhWorkspace();
 }
@@ -220,7 +241,7 @@ int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const InstShade* shade,
     return RT_OK;
 }
 
-int lbvh_build(hipStream_t s, LbvhWorkspace& w, u32 n, int leaf_max, bool tlas, BvhNode* nodes_out, u32* perm_out) {
+int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, int builder, u32 n, int leaf_max, bool tlas, BvhNode* nodes_out, u32* perm_out) {
     if (n == 0 || n > w.capacity) { set_error("lbvh_build: bad primitive count %u", n); return RT_ERR_INVALID; }
     hipLaunchKernelGGL(k_scene_box, dim3(1), dim3(1024), 0, s, w.boxes, n, w.scene_box);
     hipLaunchKernelGGL(k_morton, grid_for(n), dim3(BT), 0, s, w.boxes, w.scene_box, n, w.keys, w.vals);
@@ -232,13 +253,14 @@ int lbvh_build(hipStream_t s, LbvhWorkspace& w, u32 n, int leaf_max, bool tlas, 
         RT_HIP(hipGetLastError());
         return RT_OK;
     }
+    if (builder == 1 && pw) return ploc_build(s, w, *pw, n, leaf_max, tlas, nodes_out, perm_out);
     RT_HIP(hipMemsetAsync(w.flags, 0, (size_t) n * 4, s));
     RT_HIP(hipMemsetAsync(w.depth, 0, (size_t) n * 4, s));
     hipLaunchKernelGGL(k_hierarchy, grid_for(n - 1), dim3(BT), 0, s, w.keys, (int) n, w.build_nodes, w.leaf_parent);
     hipLaunchKernelGGL(k_refit, grid_for(n), dim3(BT), 0, s, w.boxes, perm_out, (int) n, w.build_nodes, w.leaf_parent,
-                       w.node_boxes, w.depth, w.flags);
+                       w.node_boxes, w.depth, w.flags, w.cost, w.collapsed, leaf_max);
     hipLaunchKernelGGL(k_emit, grid_for(n - 1), dim3(BT), 0, s, w.boxes, perm_out, (int) n, w.build_nodes, w.node_boxes,
-                       w.depth, w.scene_box, leaf_max, tlas ? 1 : 0, nodes_out);
+                       w.depth, w.scene_box, w.collapsed, tlas ? 1 : 0, nodes_out);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

@@ -78,12 +78,16 @@ RT_DEV void aabb_union(Aabb& a, const Aabb& b) {
     for (int k = 0; k < 3; k++) { a.lo[k] = fminf(a.lo[k], b.lo[k]); a.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
 }
 
-// link + box of one child for the traversal node.  `leaf_max` sorted primitives at most are merged into a leaf;
-// tlas: leaf link = ~(original instance index) and leaf_max must be 1.
-RT_DEV int lbvh_child_link(int child, const BuildNode* bn, const u32* perm, int leaf_max, bool tlas) {
+// link of one child for the traversal node: an internal child whose subtree was marked `collapsed` (cheaper as one
+// leaf by the surface-area heuristic, at most 8 primitives) becomes a leaf over its contiguous sorted range.
+// tlas: leaf link = ~(original instance index); TLAS subtrees are never collapsed (leaf_max 1).
+RT_DEV int lbvh_child_link(int child, const BuildNode* bn, const u32* perm, const u32* collapsed, bool tlas) {
     int first, count;
     if (child < 0) { first = ~child; count = 1; }
-    else { first = bn[child].first; count = bn[child].last - bn[child].first + 1; if (count > leaf_max) return child; }
+    else {
+        if (!collapsed[child]) return child;
+        first = bn[child].first; count = bn[child].last - bn[child].first + 1;
+    }
     if (tlas) return ~((int) perm[first]);
     return ~((first << 3) | (count - 1));
 }

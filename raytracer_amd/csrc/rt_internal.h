@@ -40,18 +40,34 @@ struct LbvhWorkspace {
     int* leaf_parent = nullptr;
     u32* flags = nullptr;
     int* depth = nullptr;
+    float* cost = nullptr;
+    u32* collapsed = nullptr;
     void* sort_scratch = nullptr;
     u32 capacity = 0;
 };
 int lbvh_workspace_reserve(LbvhWorkspace& w, u32 n);
 void lbvh_workspace_free(LbvhWorkspace& w);
 
+struct PlocWorkspace { // rt_ploc.hip
+    int* cid[2] = { nullptr, nullptr };
+    rtd::Aabb* cbox[2] = { nullptr, nullptr };
+    int* nn = nullptr;
+    unsigned long long *excl = nullptr, *sums = nullptr;
+    u32* totals = nullptr;
+    u32* leaf_first = nullptr;
+    u32 capacity = 0;
+};
+int ploc_workspace_reserve(PlocWorkspace& w, u32 n);
+void ploc_workspace_free(PlocWorkspace& w);
+int ploc_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace& pw, u32 n, int leaf_max, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
+
 // boxes for the n triangles of a BLAS -> w.boxes
 int lbvh_triangle_boxes(hipStream_t s, LbvhWorkspace& w, const RtVertex* verts, const uint16_t* indices, u32 n_tris);
 // world boxes of n instances (8 corners of each BLAS root box through object_to_world, padded) -> w.boxes
 int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const rtd::InstShade* shade, const rtd::InstRec* insts, u32 n);
 // builds the hierarchy over w.boxes[0..n); nodes_out has max(1, n-1) entries; perm_out[n] = sorted -> original.
-int lbvh_build(hipStream_t s, LbvhWorkspace& w, u32 n, int leaf_max, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
+// builder: 0 = Karras LBVH hierarchy, 1 = PLOC agglomerative clustering (pw required)
+int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, int builder, u32 n, int leaf_max, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
 // TriRec array in leaf order
 int lbvh_write_trirecs(hipStream_t s, const u32* perm, const RtVertex* verts, const uint16_t* indices,
                        const u32* tri_geometry, const rtd::GeomRec* geoms, u32 n_tris, rtd::TriRec* out);
@@ -106,7 +122,7 @@ struct PassArgs {
 
 int launch_camera_raygen(hipStream_t s, const PassArgs& a, u32 sample_index);
 int launch_probe_raygen(hipStream_t s, const PassArgs& a, u32 sample_index);
-int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal);
+int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, int variant);
 int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index);
 int launch_gather(hipStream_t s, const PassArgs& a);
 int launch_camera_resolve(hipStream_t s, const PassArgs& a);

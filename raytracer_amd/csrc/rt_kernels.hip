@@ -201,8 +201,8 @@ __global__ __launch_bounds__(BT) void k_probe_resolve(PassArgs a) {
 }
 
 // ---- TraceRay ---------------------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ __launch_bounds__(TRAVERSE_WAVE) void k_traverse(PassArgs a, u32 inq) {
+template <bool COUNT, int MODE, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq) {
     __shared__ int smem[LDS_STACK_DEPTH * TRAVERSE_WAVE];
     const u32 seg = blockIdx.x / (SEG / TRAVERSE_WAVE);
     const u32 idx = (blockIdx.x % (SEG / TRAVERSE_WAVE)) * TRAVERSE_WAVE + threadIdx.x;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(TRAVERSE_WAVE) void k_traverse(PassArgs a, u32 inq)
         f3 d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
         LaneStack st; st.lds = &smem[threadIdx.x]; st.sp = 0;
         HitOut h;
-        trace_closest<LaneStack, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, h, cnt);
+        trace_closest<LaneStack, COUNT, MODE>(a.scene, o, d, a.tmin, a.tmax, st, h, cnt);
         a.hits.t[qi] = h.t; a.hits.u[qi] = h.u; a.hits.v[qi] = h.v; a.hits.inst[qi] = h.inst; a.hits.tri[qi] = h.tri;
     }
     if (COUNT) {
@@ -369,11 +369,18 @@ int launch_probe_raygen(hipStream_t s, const PassArgs& a, u32 sample_index) {
     return RT_OK;
 }
 static size_t pass_paths(const PassArgs& a) { return (size_t) a.n_segments * SEG; }
-int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal) {
+int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, int variant) {
     size_t n = pass_paths(a);
     if (!n) return RT_OK;
-    if (count_traversal) hipLaunchKernelGGL(k_traverse<true>, blocks(n, TRAVERSE_WAVE), dim3(TRAVERSE_WAVE), 0, s, a, in_queue);
-    else hipLaunchKernelGGL(k_traverse<false>, blocks(n, TRAVERSE_WAVE), dim3(TRAVERSE_WAVE), 0, s, a, in_queue);
+    dim3 grid = blocks(n, TRAVERSE_WAVE), block(TRAVERSE_WAVE);
+    if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, 1>), grid, block, 0, s, a, in_queue);
+    else switch (variant) {
+        case 0: hipLaunchKernelGGL((k_traverse<false, 0, 1>), grid, block, 0, s, a, in_queue); break;
+        case 2: hipLaunchKernelGGL((k_traverse<false, 1, 6>), grid, block, 0, s, a, in_queue); break;
+        case 3: hipLaunchKernelGGL((k_traverse<false, 1, 8>), grid, block, 0, s, a, in_queue); break;
+        case 4: hipLaunchKernelGGL((k_traverse<false, 0, 8>), grid, block, 0, s, a, in_queue); break;
+        default: hipLaunchKernelGGL((k_traverse<false, 1, 1>), grid, block, 0, s, a, in_queue); break;
+    }
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

@@ -1,0 +1,248 @@
+// rt_ploc.hip -- BVH topology by parallel locally-ordered clustering (PLOC, Meister & Bittner 2018) on gfx950.
+//
+// Primitives are sorted along the Morton curve (rt_bvh.hip); then, repeatedly, every cluster looks at its 2*R
+// neighbours in the current order, picks the one whose union with it has the smallest surface area, and mutual pairs
+// merge into a new inner node.  Compared with the Karras LBVH split-by-bit hierarchy this is an agglomerative
+// surface-area build: it cut the triangles tested per ray by 2-3x on the reference's scenes.
+// Boxes, subtree sizes, depth and the SAH leaf-collapse decision are known at merge time, so there is no refit pass
+// and no inter-workgroup hand-off inside a launch: every step is its own kernel and numbering comes from prefix
+// scans, which also makes the tree bit-reproducible from run to run.
+#include "rt_internal.h"
+
+namespace rti {
+
+using namespace rtd;
+
+static constexpr int BT = 256;
+static constexpr int SCAN_BLOCK = 1024;
+static constexpr int PLOC_RADIUS = 8;
+static inline dim3 grid_for(u32 n, int bt = BT) { return dim3((n + bt - 1) / bt); }
+
+#define RT_SAH_NODE 1.0f
+#define RT_SAH_TRI  1.3f
+
+RT_DEV float ploc_half_area(const Aabb& b) {
+    float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
+    return ex * ey + ey * ez + ez * ex;
+}
+RT_DEV Aabb ploc_union(const Aabb& a, const Aabb& b) {
+    Aabb r;
+    for (int k = 0; k < 3; k++) { r.lo[k] = fminf(a.lo[k], b.lo[k]); r.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+    return r;
+}
+
+__global__ void k_ploc_init(const Aabb* __restrict__ boxes, const u32* __restrict__ vals, u32 n, int* __restrict__ cid,
+                            Aabb* __restrict__ cbox) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    cid[i] = ~(int) i;
+    cbox[i] = boxes[vals[i]];
+}
+
+// nearest neighbour by merged surface area within +-PLOC_RADIUS positions (ties: the lower position)
+__global__ void k_ploc_nn(const Aabb* __restrict__ cbox, u32 m, int* __restrict__ nn) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int) m) return;
+    Aabb me = cbox[i];
+    int j0 = i - PLOC_RADIUS < 0 ? 0 : i - PLOC_RADIUS, j1 = i + PLOC_RADIUS >= (int) m ? (int) m - 1 : i + PLOC_RADIUS;
+    float best = 3.4e38f; int bj = -1;
+    for (int j = j0; j <= j1; j++) {
+        if (j == i) continue;
+        float a = ploc_half_area(ploc_union(me, cbox[j]));
+        if (a < best || bj < 0) { best = a; bj = j; }
+    }
+    nn[i] = bj;
+}
+
+// flags of position i: low word = survives into the next round, high word = creates a node (lower index of a mutual pair)
+RT_DEV unsigned long long ploc_flags(const int* nn, int i) {
+    int j = nn[i];
+    bool mutual = j >= 0 && nn[j] == i;
+    unsigned long long valid = (mutual && j < i) ? 0ull : 1ull;
+    unsigned long long merge = (mutual && i < j) ? 1ull : 0ull;
+    return valid | (merge << 32);
+}
+
+RT_DEV unsigned long long wave_inclusive_scan64(unsigned long long v, u32 lane) {
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned long long t = __shfl_up(v, off);
+        if ((int) lane >= off) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of the flags inside one 1024-wide block; block totals to sums[]
+__global__ __launch_bounds__(SCAN_BLOCK) void k_ploc_scan_block(const int* __restrict__ nn, u32 m, unsigned long long* __restrict__ excl,
+                                                                unsigned long long* __restrict__ sums) {
+    __shared__ unsigned long long s_wave[SCAN_BLOCK / 64];
+    u32 i = blockIdx.x * SCAN_BLOCK + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long f = i < m ? ploc_flags(nn, (int) i) : 0ull;
+    unsigned long long inc = wave_inclusive_scan64(f, lane);
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0, total = 0;
+    for (u32 w = 0; w < SCAN_BLOCK / 64; w++) { unsigned long long c = s_wave[w]; if (w < wave) base += c; total += c; }
+    if (i < m) excl[i] = base + inc - f;
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// exclusive scan of the block totals (one workgroup); totals[0] = clusters left, totals[1] = nodes created
+__global__ __launch_bounds__(SCAN_BLOCK) void k_ploc_scan_sums(unsigned long long* __restrict__ sums, u32 nblocks, u32* __restrict__ totals) {
+    __shared__ unsigned long long s_wave[SCAN_BLOCK / 64];
+    __shared__ unsigned long long s_carry;
+    u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u32 b0 = 0; b0 < nblocks; b0 += SCAN_BLOCK) {
+        u32 i = b0 + threadIdx.x;
+        unsigned long long f = i < nblocks ? sums[i] : 0ull;
+        unsigned long long inc = wave_inclusive_scan64(f, lane);
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        unsigned long long base = s_carry, total = 0;
+        for (u32 w = 0; w < SCAN_BLOCK / 64; w++) { unsigned long long c = s_wave[w]; if (w < wave) base += c; total += c; }
+        if (i < nblocks) sums[i] = base + inc - f;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { totals[0] = (u32) (s_carry & 0xffffffffull); totals[1] = (u32) (s_carry >> 32); }
+}
+
+__global__ void k_ploc_apply(const int* __restrict__ cid, const Aabb* __restrict__ cbox, const int* __restrict__ nn, u32 m,
+                             const unsigned long long* __restrict__ excl, const unsigned long long* __restrict__ sums, u32 node_base,
+                             int leaf_max, int* __restrict__ cid_out, Aabb* __restrict__ cbox_out, BuildNode* __restrict__ bn,
+                             int* __restrict__ leaf_parent, Aabb* __restrict__ node_boxes, u32* __restrict__ size, int* __restrict__ depth,
+                             float* __restrict__ cost, u32* __restrict__ collapsed) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int) m) return;
+    int j = nn[i];
+    bool mutual = j >= 0 && nn[j] == i;
+    if (mutual && j < i) return; // absorbed by the lower position
+    unsigned long long off = excl[i] + sums[i / SCAN_BLOCK];
+    u32 pos = (u32) (off & 0xffffffffull);
+    if (!mutual) { cid_out[pos] = cid[i]; cbox_out[pos] = cbox[i]; return; }
+    u32 k = node_base + (u32) (off >> 32);
+    int l = cid[i], r = cid[j];
+    Aabb bl = cbox[i], br = cbox[j], b = ploc_union(bl, br);
+    BuildNode nd; nd.left = l; nd.right = r; nd.first = 0; nd.last = 0; nd.parent = -1;
+    bn[k] = nd;
+    u32 sl = 1, sr = 1; int dl = 0, dr = 0; float cl, cr;
+    if (l < 0) { leaf_parent[~l] = (int) k; cl = RT_SAH_TRI * ploc_half_area(bl); } else { bn[l].parent = (int) k; sl = size[l]; dl = depth[l]; cl = cost[l]; }
+    if (r < 0) { leaf_parent[~r] = (int) k; cr = RT_SAH_TRI * ploc_half_area(br); } else { bn[r].parent = (int) k; sr = size[r]; dr = depth[r]; cr = cost[r]; }
+    node_boxes[k] = b;
+    size[k] = sl + sr;
+    depth[k] = 1 + (dl > dr ? dl : dr);
+    float a = ploc_half_area(b);
+    float split_cost = RT_SAH_NODE * a + cl + cr, leaf_cost = RT_SAH_TRI * (float) (sl + sr) * a;
+    bool col = (int) (sl + sr) <= leaf_max && leaf_cost <= split_cost;
+    collapsed[k] = col ? 1u : 0u;
+    cost[k] = col ? leaf_cost : split_cost;
+    cid_out[pos] = (int) k;
+    cbox_out[pos] = b;
+}
+
+// position of every subtree in depth-first leaf order: leaves of a collapsed subtree become one contiguous leaf range
+__global__ void k_ploc_first(int n, BuildNode* __restrict__ bn, const int* __restrict__ leaf_parent, const u32* __restrict__ size,
+                             const u32* __restrict__ vals, u32* __restrict__ leaf_first, u32* __restrict__ perm_out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n - 1) return;
+    bool is_leaf = t < n;
+    int self = is_leaf ? ~t : t - n;
+    int p = is_leaf ? leaf_parent[t] : bn[t - n].parent;
+    u32 pos = 0;
+    int child = self;
+    while (p >= 0) {
+        if (bn[p].right == child) { int l = bn[p].left; pos += l < 0 ? 1u : size[l]; }
+        child = p;
+        p = bn[p].parent;
+    }
+    if (is_leaf) { leaf_first[t] = pos; perm_out[pos] = vals[t]; }
+    else { bn[t - n].first = (int) pos; bn[t - n].last = (int) (pos + size[t - n] - 1); }
+}
+
+RT_DEV int ploc_link(int child, int n, const BuildNode* bn, const u32* collapsed, const u32* size, const u32* leaf_first,
+                     const u32* vals, bool tlas) {
+    if (child < 0) return tlas ? ~(int) vals[~child] : ~(int) ((leaf_first[~child] << 3) | 0u);
+    if (collapsed[child]) return ~(int) (((u32) bn[child].first << 3) | (size[child] - 1u));
+    return (n - 2) - child; // the root (created last) becomes node 0
+}
+
+__global__ void k_ploc_emit(int n, const BuildNode* __restrict__ bn, const Aabb* __restrict__ boxes, const u32* __restrict__ vals,
+                            const Aabb* __restrict__ node_boxes, const u32* __restrict__ collapsed, const u32* __restrict__ size,
+                            const u32* __restrict__ leaf_first, const int* __restrict__ depth, const Aabb* __restrict__ scene, int tlas,
+                            BvhNode* __restrict__ out) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n - 1) return;
+    int l = bn[k].left, r = bn[k].right;
+    BvhNode nd;
+    Aabb b0 = l < 0 ? boxes[vals[~l]] : node_boxes[l], b1 = r < 0 ? boxes[vals[~r]] : node_boxes[r];
+    set_box(nd.lo0, nd.hi0, b0);
+    set_box(nd.lo1, nd.hi1, b1);
+    nd.c0 = ploc_link(l, n, bn, collapsed, size, leaf_first, vals, tlas != 0);
+    nd.c1 = ploc_link(r, n, bn, collapsed, size, leaf_first, vals, tlas != 0);
+    nd.bound = 0.0f; nd.depth = 0;
+    if (k == n - 2) {
+        float m = 0.0f;
+        for (int c = 0; c < 3; c++) m = fmaxf(m, fmaxf(fabsf(scene->lo[c]), fabsf(scene->hi[c])));
+        nd.bound = m; nd.depth = depth[k];
+    }
+    out[(n - 2) - k] = nd;
+}
+
+int ploc_workspace_reserve(PlocWorkspace& w, u32 n) {
+    if (n <= w.capacity) return RT_OK;
+    ploc_workspace_free(w);
+    u32 cap = n < 1024 ? 1024 : n;
+    for (int k = 0; k < 2; k++) {
+        RT_HIP(hipMalloc(&w.cid[k], 4 * (size_t) cap));
+        RT_HIP(hipMalloc(&w.cbox[k], sizeof(Aabb) * (size_t) cap));
+    }
+    RT_HIP(hipMalloc(&w.nn, 4 * (size_t) cap));
+    RT_HIP(hipMalloc(&w.excl, 8 * (size_t) cap));
+    RT_HIP(hipMalloc(&w.sums, 8 * (size_t) ((cap + SCAN_BLOCK - 1) / SCAN_BLOCK)));
+    RT_HIP(hipMalloc(&w.totals, 2 * sizeof(u32)));
+    RT_HIP(hipMalloc(&w.leaf_first, 4 * (size_t) cap));
+    w.capacity = cap;
+    return RT_OK;
+}
+
+void ploc_workspace_free(PlocWorkspace& w) {
+    void* ptrs[] = { w.cid[0], w.cid[1], w.cbox[0], w.cbox[1], w.nn, w.excl, w.sums, w.totals, w.leaf_first };
+    for (void* p : ptrs) if (p) (void) hipFree(p);
+    w = PlocWorkspace();
+}
+
+// topology + boxes + leaf order over the n Morton-sorted primitives (w.vals = sorted -> original, w.boxes = original order)
+int ploc_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace& pw, u32 n, int leaf_max, bool tlas, BvhNode* nodes_out, u32* perm_out) {
+    int rc = ploc_workspace_reserve(pw, n);
+    if (rc != RT_OK) return rc;
+    hipLaunchKernelGGL(k_ploc_init, grid_for(n), dim3(BT), 0, s, w.boxes, w.vals, n, pw.cid[0], pw.cbox[0]);
+    u32 m = n, node_base = 0;
+    int cur = 0;
+    for (int iter = 0; m > 1; iter++) {
+        if (iter > 4096) { set_error("ploc_build: no convergence"); return RT_ERR_DEVICE; }
+        u32 nblocks = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        hipLaunchKernelGGL(k_ploc_nn, grid_for(m), dim3(BT), 0, s, pw.cbox[cur], m, pw.nn);
+        hipLaunchKernelGGL(k_ploc_scan_block, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, pw.nn, m, pw.excl, pw.sums);
+        hipLaunchKernelGGL(k_ploc_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, pw.sums, nblocks, pw.totals);
+        hipLaunchKernelGGL(k_ploc_apply, grid_for(m), dim3(BT), 0, s, pw.cid[cur], pw.cbox[cur], pw.nn, m, pw.excl, pw.sums, node_base,
+                           leaf_max, pw.cid[cur ^ 1], pw.cbox[cur ^ 1], w.build_nodes, w.leaf_parent, w.node_boxes, w.flags, w.depth,
+                           w.cost, w.collapsed);
+        u32 totals[2];
+        RT_HIP(hipMemcpyAsync(totals, pw.totals, sizeof totals, hipMemcpyDeviceToHost, s));
+        RT_HIP(hipStreamSynchronize(s));
+        if (totals[1] == 0 || totals[0] + totals[1] != m) { set_error("ploc_build: inconsistent round (%u -> %u + %u)", m, totals[0], totals[1]); return RT_ERR_DEVICE; }
+        m = totals[0]; node_base += totals[1];
+        cur ^= 1;
+    }
+    if (node_base != n - 1) { set_error("ploc_build: %u nodes for %u primitives", node_base, n); return RT_ERR_DEVICE; }
+    hipLaunchKernelGGL(k_ploc_first, grid_for(2 * n - 1), dim3(BT), 0, s, (int) n, w.build_nodes, w.leaf_parent, w.flags, w.vals,
+                       pw.leaf_first, perm_out);
+    hipLaunchKernelGGL(k_ploc_emit, grid_for(n - 1), dim3(BT), 0, s, (int) n, w.build_nodes, w.boxes, w.vals, w.node_boxes, w.collapsed,
+                       w.flags, pw.leaf_first, w.depth, w.scene_box, tlas ? 1 : 0, nodes_out);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+} // namespace rti
