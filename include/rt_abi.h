@@ -126,6 +126,9 @@ typedef struct RtStats {
     double   tlas_build_ms;
     uint64_t blas_triangles;       /* triangles in all BLASes                                               */
     uint64_t tlas_instances;
+    uint64_t wave_node_steps;      /* with RT_FLAG_COUNT_TRAVERSAL: node / triangle / instance steps counted once per   */
+    uint64_t wave_tri_steps;       /* 64-lane wave; lane steps / (64 * wave steps) = SIMD efficiency of the traversal    */
+    uint64_t wave_instance_steps;
 } RtStats;
 
 /* rt_set_flags bits */

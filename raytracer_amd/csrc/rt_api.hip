@@ -77,7 +77,7 @@ struct rt_ctx {
     int traverse_variant = 1; // RT_TRAVERSE_VARIANT: kernel A/B switch (tuning aid)
     // path buffers
     u32 n_paths = 0; float* d_arena = nullptr;
-    RayQueue q[2]; HitBuf hits; PathState ps; GatherQueue gq;
+    RayQueue q[2]; HitBuf hits; PathState ps; GatherQueue gq; int* d_stack_spill = nullptr;
     u32* d_seg_count = nullptr; u32 n_segments_cap = 0; DeviceStats* d_stats = nullptr;
     // BSSRDF tables
     float* d_table[2] = { nullptr, nullptr }; int table_texels[2] = { 0, 0 }; int profile = 0;
@@ -114,7 +114,7 @@ int ensure_path_buffers(rt_ctx* c) {
     RT_HIP(hipMalloc(&c->d_seg_count, 3 * sizeof(u32) * (size_t) segs));
     RT_HIP(hipMemset(c->d_seg_count, 0, 3 * sizeof(u32) * (size_t) segs));
     c->n_segments_cap = segs;
-    const int n_arrays = 14 /* 2 queues x (6 + path) */ + 5 /* hits */ + 15 /* path state */ + 9 /* gather */;
+    const int n_arrays = 14 /* 2 queues x (6 + path) */ + 5 /* hits */ + 15 /* path state */ + 9 /* gather */ + 32 /* stack spill */;
     size_t stride = ((size_t) need + 63) & ~(size_t) 63;
     RT_HIP(hipMalloc(&c->d_arena, stride * 4 * n_arrays));
     float* p = c->d_arena;
@@ -131,7 +131,8 @@ int ensure_path_buffers(rt_ctx* c) {
     c->ps.sum_x = take(); c->ps.sum_y = take(); c->ps.sum_z = take(); c->ps.sum_a = take();
     c->gq.path = (u32*) take(); c->gq.hx = take(); c->gq.hy = take(); c->gq.hz = take(); c->gq.tf = take();
     c->gq.kx = take(); c->gq.ky = take(); c->gq.kz = take(); c->gq.ti = (int*) take();
-    c->n_paths = need;
+    c->d_stack_spill = (int*) p; p += 32 * stride;
+    c->n_paths = (u32) stride;
     return RT_OK;
 }
 
@@ -162,6 +163,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.gather_enabled = (!probe && c->n_points > 0 && a.fudge != 0.0f) ? 1u : 0u;
     a.seg_count[0] = c->d_seg_count; a.seg_count[1] = c->d_seg_count + c->n_segments_cap;
     a.gseg_count = c->d_seg_count + 2 * (size_t) c->n_segments_cap;
+    a.stack_spill = c->d_stack_spill;
     a.stats = c->d_stats;
     a.capture = nullptr;
     a.accumulator = c->d_accumulator; a.render_target = c->d_render_target;
@@ -665,6 +667,7 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
     memset(out, 0, sizeof *out);
     out->rays_camera = ds.rays_camera; out->rays_probe = ds.rays_probe; out->gather_pairs = ds.gather_pairs;
     out->nodes_visited = ds.nodes; out->tris_tested = ds.tris; out->instances_entered = ds.insts;
+    out->wave_node_steps = ds.node_trips; out->wave_tri_steps = ds.tri_trips; out->wave_instance_steps = ds.inst_trips;
     out->traverse_launches = c->traverse_launches; out->traverse_ms = c->traverse_ms;
     out->blas_build_ms = c->blas_build_ms; out->tlas_build_ms = c->tlas_build_ms;
     out->blas_triangles = c->blas_triangles; out->tlas_instances = c->n_instances;

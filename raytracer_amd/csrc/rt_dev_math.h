@@ -14,7 +14,17 @@
 
 #if defined(__HIPCC__)
 #define RT_DEV __device__ __forceinline__
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// explicit address spaces: pointers that were loaded from memory (instance records) or merged in a phi are "flat" to
+// the compiler, and flat_load/flat_store are slower than global_load / ds_read and serialise the wait counters
+#define RT_GLOBAL __attribute__((address_space(1)))
+#define RT_LDS    __attribute__((address_space(3)))
 #else
+#define RT_GLOBAL
+#define RT_LDS
+#endif
+#if !defined(__HIPCC__)
 #define RT_DEV inline
 #endif
 

@@ -47,7 +47,15 @@ struct HitOut {
     u32 prim_global;
 };
 
-struct TraverseCounters { u32 nodes, tris, insts; };
+struct TraverseCounters { u32 nodes, tris, insts; u32 node_trips, tri_trips, inst_trips; }; // *_trips: once per wave per step
+
+RT_DEV bool first_active_lane() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __lane_id() == (unsigned) (__ffsll((long long) __ballot(1)) - 1);
+#else
+    return true;
+#endif
+}
 
 // parameters of the (non-spec, conservative) ray/box test for one level
 struct BoxRay {
@@ -95,7 +103,7 @@ RT_DEV bool box_test(const BoxRay& r, const float* lo, const float* hi, float tm
 // 16-byte loads: nodes, triangles and instance records are fetched as whole 16-byte quads (coalescer-friendly,
 // 4 / 3 / 4 load instructions per record instead of one per float)
 struct alignas(16) Quad { float x, y, z, w; };
-RT_DEV Quad ldq(const void* base, int quad_index) { return reinterpret_cast<const Quad*>(base)[quad_index]; }
+RT_DEV Quad ldq(const RT_GLOBAL void* base, int quad_index) { return ((const RT_GLOBAL Quad*) base)[quad_index]; }
 
 #define RT_TRAVERSAL_DONE ((int) 0x80000001)
 
@@ -110,9 +118,12 @@ RT_DEV void trace_closest(const SceneView& sc, f3 o, f3 d, float tmin, float tma
     best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.inst = -1; best.tri = -1; best.prim_global = 0;
     bool have_hit = false;
 
-    const BvhNode* nodes = sc.tlas_nodes;
-    const TriRec* tris = nullptr;
-    BoxRay br = make_box_ray(o, d, sc.tlas_nodes[0].bound);
+    const RT_GLOBAL BvhNode* const tlas_nodes = (const RT_GLOBAL BvhNode*) sc.tlas_nodes;
+    const RT_GLOBAL InstRec* const insts = (const RT_GLOBAL InstRec*) sc.insts;
+    const RT_GLOBAL BvhNode* nodes = tlas_nodes;
+    const RT_GLOBAL TriRec* tris = nullptr;
+    const float tlas_bound = tlas_nodes[0].bound;
+    BoxRay br = make_box_ray(o, d, tlas_bound);
     RayPrep rp; rp.o = o; rp.kx = 0; rp.ky = 1; rp.kz = 2; rp.sx = rp.sy = rp.sz = 0.0f;
     bool bottom = false;
     int cur_inst = -1;
@@ -129,16 +140,16 @@ RT_DEV void trace_closest(const SceneView& sc, f3 o, f3 d, float tmin, float tma
                     cur = st.pop();
                     if (cur == RT_STACK_MARKER) { // back to the top level
                         bottom = false;
-                        nodes = sc.tlas_nodes;
-                        br = make_box_ray(o, d, sc.tlas_nodes[0].bound);
+                        nodes = tlas_nodes;
+                        br = make_box_ray(o, d, tlas_bound);
                         if (st.empty()) cur = RT_TRAVERSAL_DONE; else cur = st.pop();
                     }
                 }
             }
             if (cur < 0) break;
-            const BvhNode* n = nodes + cur;
+            const RT_GLOBAL BvhNode* n = nodes + cur;
             Quad q0 = ldq(n, 0), q1 = ldq(n, 1), q2 = ldq(n, 2), q3 = ldq(n, 3);
-            if (COUNT) cnt.nodes++;
+            if (COUNT) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; }
             float lo0[3] = { q0.x, q0.y, q0.z }, hi0[3] = { q0.w, q1.x, q1.y };
             float lo1[3] = { q1.z, q1.w, q2.x }, hi1[3] = { q2.y, q2.z, q2.w };
             float e0, e1;
@@ -159,16 +170,16 @@ RT_DEV void trace_closest(const SceneView& sc, f3 o, f3 d, float tmin, float tma
         if (!bottom) {
             // ---- TLAS leaf: enter the instance.  DXR semantics: the ray goes to object space, t is preserved ------
             cur_inst = ~cur;
-            const InstRec* in = sc.insts + cur_inst;
+            const RT_GLOBAL InstRec* in = insts + cur_inst;
             Quad m0 = ldq(in, 0), m1 = ldq(in, 1), m2 = ldq(in, 2), m3 = ldq(in, 3);
-            if (COUNT) cnt.insts++;
+            if (COUNT) { cnt.insts++; if (first_active_lane()) cnt.inst_trips++; }
             float w2o[12] = { m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w };
             f3 oo = xform_point43(w2o, o);
             f3 od = xform_dir43(w2o, d);
             rp = prepare_ray(oo, od);
             unsigned long long pn = ((unsigned long long) as_u32(m3.y) << 32) | as_u32(m3.x);
             unsigned long long pt = ((unsigned long long) as_u32(m3.w) << 32) | as_u32(m3.z);
-            nodes = reinterpret_cast<const BvhNode*>(pn); tris = reinterpret_cast<const TriRec*>(pt);
+            nodes = (const RT_GLOBAL BvhNode*) pn; tris = (const RT_GLOBAL TriRec*) pt;
             br = make_box_ray(oo, od, nodes[0].bound);
             st.push(RT_STACK_MARKER);
             bottom = true;
@@ -178,9 +189,9 @@ RT_DEV void trace_closest(const SceneView& sc, f3 o, f3 d, float tmin, float tma
             int v = ~cur;
             int first = v >> 3, count = (v & 7) + 1;
             for (int k = 0; k < count; k++) {
-                const TriRec* tr = tris + first + k;
+                const RT_GLOBAL TriRec* tr = tris + first + k;
                 Quad a = ldq(tr, 0), b = ldq(tr, 1), c = ldq(tr, 2);
-                if (COUNT) cnt.tris++;
+                if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
                 float t, u, w;
                 if (!intersect_triangle(rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, w)) continue;
                 if (!(t > tmin && t < tmax)) continue;

@@ -85,7 +85,7 @@ struct PathState {
 struct GatherQueue { u32* path; float *hx, *hy, *hz, *tf, *kx, *ky, *kz; int* ti; };
 
 struct DeviceStats { // lives in device memory
-    unsigned long long rays_camera, rays_probe, gather_pairs, nodes, tris, insts;
+    unsigned long long rays_camera, rays_probe, gather_pairs, nodes, tris, insts, node_trips, tri_trips, inst_trips;
 };
 
 struct PassArgs {
@@ -106,6 +106,7 @@ struct PassArgs {
     u32 gather_enabled;
     u32* seg_count[2];           // rays per segment of the two ping-pong queues
     u32* gseg_count;             // gather items per segment
+    int* stack_spill;            // [32][n_paths] overflow of the per-lane traversal stack
     DeviceStats* stats;
     RtHit* capture;              // [(bounces+1) * width*height] or null
     float* accumulator;          // RGBA32F

@@ -20,24 +20,28 @@ namespace rti {
 using namespace rtd;
 
 static constexpr int TRAVERSE_WAVE   = 64;
-static constexpr int LDS_STACK_DEPTH = 24;  // entries per lane kept in LDS
-static constexpr int OVF_STACK_DEPTH = 40;  // spill (scratch); the host checks tlas_depth + 1 + blas_depth <= 64
+static constexpr int LDS_STACK_DEPTH = 32;  // entries per lane kept in LDS (8 KB per wave: 20 waves/CU = the VGPR limit)
+static constexpr int OVF_STACK_DEPTH = 32;  // global spill; the host checks tlas_depth + 1 + blas_depth <= 64
 static constexpr int BT = 256;
 static constexpr int SEG = 1024;            // rays per queue segment = threads per raygen / shade workgroup
 
+// per-lane traversal stack: the first LDS_STACK_DEPTH entries in LDS (entries of one lane are 64 dwords apart:
+// conflict-free), deeper entries in a global spill array indexed [entry][queue slot] (touched only by the rare deep
+// path; a private array would be promoted to 32 VGPRs or drag the stack pointer into scratch).
 struct LaneStack {
-    int* lds;   // &smem[lane], entries are 64 ints apart (conflict-free)
-    int  ovf[OVF_STACK_DEPTH];
-    int  sp;
+    RT_LDS int* lds;
+    RT_GLOBAL int* spill;   // &stack_spill[queue slot]
+    u32 spill_stride;
+    int sp;
     RT_DEV void push(int v) {
         if (sp < LDS_STACK_DEPTH) lds[sp * TRAVERSE_WAVE] = v;
-        else if (sp < LDS_STACK_DEPTH + OVF_STACK_DEPTH) ovf[sp - LDS_STACK_DEPTH] = v;
+        else if (sp < LDS_STACK_DEPTH + OVF_STACK_DEPTH) spill[(size_t) (sp - LDS_STACK_DEPTH) * spill_stride] = v;
         sp++;
     }
     RT_DEV int pop() {
         sp--;
         if (sp < LDS_STACK_DEPTH) return lds[sp * TRAVERSE_WAVE];
-        if (sp < LDS_STACK_DEPTH + OVF_STACK_DEPTH) return ovf[sp - LDS_STACK_DEPTH];
+        if (sp < LDS_STACK_DEPTH + OVF_STACK_DEPTH) return spill[(size_t) (sp - LDS_STACK_DEPTH) * spill_stride];
         return RT_STACK_MARKER; // unreachable when the host-side depth check holds
     }
     RT_DEV bool empty() const { return sp == 0; }
@@ -214,12 +218,13 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
         if (threadIdx.x == 0) atomicAdd(a.probe ? &a.stats->rays_probe : &a.stats->rays_camera, (unsigned long long) sum);
     }
     const u32 qi = seg * SEG + idx;
-    TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0;
+    TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
     if (idx < n) {
         const RayQueue& q = a.q[inq];
         f3 o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
         f3 d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
-        LaneStack st; st.lds = &smem[threadIdx.x]; st.sp = 0;
+        LaneStack st; st.lds = (RT_LDS int*) &smem[threadIdx.x]; st.spill = (RT_GLOBAL int*) (a.stack_spill + qi);
+        st.spill_stride = a.n_paths; st.sp = 0;
         HitOut h;
         trace_closest<LaneStack, COUNT, MODE>(a.scene, o, d, a.tmin, a.tmax, st, h, cnt);
         a.hits.t[qi] = h.t; a.hits.u[qi] = h.u; a.hits.v[qi] = h.v; a.hits.inst[qi] = h.inst; a.hits.tri[qi] = h.tri;
@@ -230,6 +235,12 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
             atomicAdd(&a.stats->nodes, (unsigned long long) sn);
             atomicAdd(&a.stats->tris, (unsigned long long) stt);
             atomicAdd(&a.stats->insts, (unsigned long long) si);
+        }
+        u32 tn = wave_sum(cnt.node_trips), tt = wave_sum(cnt.tri_trips), ti = wave_sum(cnt.inst_trips);
+        if (threadIdx.x == 0) {
+            atomicAdd(&a.stats->node_trips, (unsigned long long) tn);
+            atomicAdd(&a.stats->tri_trips, (unsigned long long) tt);
+            atomicAdd(&a.stats->inst_trips, (unsigned long long) ti);
         }
     }
 }
@@ -379,7 +390,8 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
         case 2: hipLaunchKernelGGL((k_traverse<false, 1, 6>), grid, block, 0, s, a, in_queue); break;
         case 3: hipLaunchKernelGGL((k_traverse<false, 1, 8>), grid, block, 0, s, a, in_queue); break;
         case 4: hipLaunchKernelGGL((k_traverse<false, 0, 8>), grid, block, 0, s, a, in_queue); break;
-        default: hipLaunchKernelGGL((k_traverse<false, 1, 1>), grid, block, 0, s, a, in_queue); break;
+        case 5: hipLaunchKernelGGL((k_traverse<false, 1, 1>), grid, block, 0, s, a, in_queue); break;
+        default: hipLaunchKernelGGL((k_traverse<false, 1, 5>), grid, block, 0, s, a, in_queue); break;
     }
     RT_HIP(hipGetLastError());
     return RT_OK;

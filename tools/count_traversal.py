@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Per-ray traversal counters and SIMD efficiency of k_traverse for the benchmark workloads."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracer_amd import api, scenes, distributed, _abi
+for name, sc in [("c2", scenes.bunny(1920, 1080, 1, 1)), ("c3", scenes.cornell(1920, 1080, 2, 4)), ("c4", scenes.cornell_bunny(1920, 1080, 1, 4))]:
+    rt = api.Raytracer(0); sc.setup(rt, _abi.RT_FLAG_COUNT_TRAVERSAL)
+    rt.reset_stats()
+    distributed.render_frame(rt, sc.globals, 0, 5); distributed.render_frame(rt, sc.globals, 1, 5)
+    s = rt.get_stats(); rays = s["rays_camera"] + s["rays_probe"]
+    print("%s rays %d | per ray: nodes %.2f tris %.2f insts %.2f | per wave-of-64-rays steps: node %.1f tri %.1f inst %.1f | SIMD eff node %.2f tri %.2f inst %.2f" % (
+        name, rays, s["nodes_visited"] / rays, s["tris_tested"] / rays, s["instances_entered"] / rays,
+        s["wave_node_steps"] / (rays / 64), s["wave_tri_steps"] / (rays / 64), s["wave_instance_steps"] / (rays / 64),
+        s["nodes_visited"] / max(1, 64 * s["wave_node_steps"]), s["tris_tested"] / max(1, 64 * s["wave_tri_steps"]),
+        s["instances_entered"] / max(1, 64 * s["wave_instance_steps"])), flush=True)
+    rt.close()
