@@ -54,7 +54,7 @@ template <typename T> void dev_free(T*& p) { if (p) { (void) hipFree(p); p = nul
 struct rt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    LbvhWorkspace lbvh; PlocWorkspace ploc; int bvh_builder = 1; // RT_BVH_BUILDER: 0 LBVH, 1 PLOC
+    LbvhWorkspace lbvh; PlocWorkspace ploc; int bvh_builder = 1; float sah_tri = 1.3f; // RT_BVH_BUILDER: 0 LBVH, 1 PLOC; RT_SAH_TRI
     std::vector<Blas> blas;
     std::vector<TranslucentMesh> translucent_meshes;
     std::vector<float> translucent_mean_area; // g_translucent_properties
@@ -262,6 +262,7 @@ int rt_create(const int* devices, int n, rt_ctx** out) {
     c->device = devices[0];
     if (const char* v = getenv("RT_TRAVERSE_VARIANT")) c->traverse_variant = atoi(v);
     if (const char* v = getenv("RT_BVH_BUILDER")) c->bvh_builder = atoi(v);
+    if (const char* v = getenv("RT_SAH_TRI")) c->sah_tri = (float) atof(v);
     RT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     RT_HIP(hipMalloc(&c->d_stats, sizeof(DeviceStats)));
@@ -401,7 +402,7 @@ int rt_build_blas(rt_ctx* c, const RtGeometry* geometries, int n, rt_blas* out) 
     int rc = lbvh_workspace_reserve(c->lbvh, b.n_tris); if (rc) return rc;
     RT_HIP(hipEventRecord(e0, c->stream));
     rc = lbvh_triangle_boxes(c->stream, c->lbvh, b.d_verts, b.d_indices, b.n_tris); if (rc) return rc;
-    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, c->bvh_builder, b.n_tris, RT_LEAF_MAX_TRIS, false, b.d_nodes, b.d_perm); if (rc) return rc;
+    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, c->bvh_builder, c->sah_tri, b.n_tris, RT_LEAF_MAX_TRIS, false, b.d_nodes, b.d_perm); if (rc) return rc;
     rc = lbvh_write_trirecs(c->stream, b.d_perm, b.d_verts, b.d_indices, b.d_tri_geometry, b.d_geoms, b.n_tris, b.d_tris); if (rc) return rc;
     RT_HIP(hipEventRecord(e1, c->stream));
     BvhNode root;
@@ -464,7 +465,7 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
     RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
     RT_HIP(hipEventRecord(e0, c->stream));
     rc = lbvh_instance_boxes(c->stream, c->lbvh, c->d_inst_shade, c->d_inst_rec, (u32) n); if (rc) return rc;
-    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, c->bvh_builder, (u32) n, 1, true, c->d_tlas_nodes, c->d_tlas_perm); if (rc) return rc;
+    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, c->bvh_builder, c->sah_tri, (u32) n, 1, true, c->d_tlas_nodes, c->d_tlas_perm); if (rc) return rc;
     RT_HIP(hipEventRecord(e1, c->stream));
     BvhNode root;
     RT_HIP(hipMemcpyAsync(&root, c->d_tlas_nodes, sizeof root, hipMemcpyDeviceToHost, c->stream));

@@ -101,13 +101,12 @@ RT_DEV float half_area(const Aabb& b) {
 }
 // surface-area-heuristic constants: one two-child node fetch+test vs one triangle fetch+test on gfx950
 #define RT_SAH_NODE 1.0f
-#define RT_SAH_TRI  1.3f
 
 // cost[] holds the un-normalised SAH cost of the best cut of each subtree; collapsed[] marks subtrees that are
 // cheaper as one leaf of <= leaf_max primitives
 __global__ void k_refit(const Aabb* __restrict__ boxes, const u32* __restrict__ perm, int n, const BuildNode* __restrict__ bn,
                         const int* __restrict__ leaf_parent, Aabb* node_boxes, int* depth, u32* flags, float* cost,
-                        u32* collapsed, int leaf_max) {
+                        u32* collapsed, int leaf_max, float sah_tri) {
     int leaf = blockIdx.x * blockDim.x + threadIdx.x;
     if (leaf >= n) return;
     int node = leaf_parent[leaf];
@@ -123,7 +122,7 @@ __global__ void k_refit(const Aabb* __restrict__ boxes, const u32* __restrict__ 
             if (child[c] < 0) {
                 const Aabb& cb = boxes[perm[~child[c]]];
                 for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], cb.lo[k]); b.hi[k] = fmaxf(b.hi[k], cb.hi[k]); }
-                child_cost += RT_SAH_TRI * half_area(cb);
+                child_cost += sah_tri * half_area(cb);
             } else {
                 child_cost += load_agent(&cost[child[c]]);
                 const Aabb* cb = &node_boxes[child[c]];
@@ -136,8 +135,8 @@ __global__ void k_refit(const Aabb* __restrict__ boxes, const u32* __restrict__ 
         depth[node] = dep + 1;
         int size = bn[node].last - bn[node].first + 1;
         float a = half_area(b);
-        float split_cost = RT_SAH_NODE * a + child_cost, leaf_cost = RT_SAH_TRI * (float) size * a;
-        bool col = size <= leaf_max && leaf_cost <= split_cost;
+        float split_cost = RT_SAH_NODE * a + child_cost, leaf_cost = sah_tri * (float) size * a;
+        bool col = size <= leaf_max && leaf_cost <= split_cost && size < n; // the root stays a node
         collapsed[node] = col ? 1u : 0u;
         cost[node] = col ? leaf_cost : split_cost;
         node = bn[node].parent;
@@ -168,7 +167,7 @@ __global__ void k_emit(const Aabb* __restrict__ boxes, const u32* __restrict__ p
     out[i] = nd;
 }
 
-// n <= leaf_max (or n == 1): a root whose first child is the only leaf
+// n == 1: a root whose first child is the only leaf
 __global__ void k_emit_single(const Aabb* __restrict__ scene, const u32* __restrict__ perm, int n, int tlas, BvhNode* __restrict__ out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     BvhNode nd;
@@ -241,24 +240,24 @@ int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const InstShade* shade,
     return RT_OK;
 }
 
-int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, int builder, u32 n, int leaf_max, bool tlas, BvhNode* nodes_out, u32* perm_out) {
+int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, BvhNode* nodes_out, u32* perm_out) {
     if (n == 0 || n > w.capacity) { set_error("lbvh_build: bad primitive count %u", n); return RT_ERR_INVALID; }
     hipLaunchKernelGGL(k_scene_box, dim3(1), dim3(1024), 0, s, w.boxes, n, w.scene_box);
     hipLaunchKernelGGL(k_morton, grid_for(n), dim3(BT), 0, s, w.boxes, w.scene_box, n, w.keys, w.vals);
     int rc = radix_sort_pairs(s, w.keys, w.vals, w.keys_tmp, w.vals_tmp, w.sort_scratch, n, 30);
     if (rc != RT_OK) return rc;
     RT_HIP(hipMemcpyAsync(perm_out, w.vals, (size_t) n * 4, hipMemcpyDeviceToDevice, s));
-    if ((int) n <= leaf_max) {
+    if (n == 1) {
         hipLaunchKernelGGL(k_emit_single, dim3(1), dim3(64), 0, s, w.scene_box, perm_out, (int) n, tlas ? 1 : 0, nodes_out);
         RT_HIP(hipGetLastError());
         return RT_OK;
     }
-    if (builder == 1 && pw) return ploc_build(s, w, *pw, n, leaf_max, tlas, nodes_out, perm_out);
+    if (builder == 1 && pw) return ploc_build(s, w, *pw, n, leaf_max, sah_tri, tlas, nodes_out, perm_out);
     RT_HIP(hipMemsetAsync(w.flags, 0, (size_t) n * 4, s));
     RT_HIP(hipMemsetAsync(w.depth, 0, (size_t) n * 4, s));
     hipLaunchKernelGGL(k_hierarchy, grid_for(n - 1), dim3(BT), 0, s, w.keys, (int) n, w.build_nodes, w.leaf_parent);
     hipLaunchKernelGGL(k_refit, grid_for(n), dim3(BT), 0, s, w.boxes, perm_out, (int) n, w.build_nodes, w.leaf_parent,
-                       w.node_boxes, w.depth, w.flags, w.cost, w.collapsed, leaf_max);
+                       w.node_boxes, w.depth, w.flags, w.cost, w.collapsed, leaf_max, sah_tri);
     hipLaunchKernelGGL(k_emit, grid_for(n - 1), dim3(BT), 0, s, w.boxes, perm_out, (int) n, w.build_nodes, w.node_boxes,
                        w.depth, w.scene_box, w.collapsed, tlas ? 1 : 0, nodes_out);
     RT_HIP(hipGetLastError());

@@ -59,7 +59,7 @@ struct PlocWorkspace { // rt_ploc.hip
 };
 int ploc_workspace_reserve(PlocWorkspace& w, u32 n);
 void ploc_workspace_free(PlocWorkspace& w);
-int ploc_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace& pw, u32 n, int leaf_max, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
+int ploc_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace& pw, u32 n, int leaf_max, float sah_tri, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
 
 // boxes for the n triangles of a BLAS -> w.boxes
 int lbvh_triangle_boxes(hipStream_t s, LbvhWorkspace& w, const RtVertex* verts, const uint16_t* indices, u32 n_tris);
@@ -67,7 +67,8 @@ int lbvh_triangle_boxes(hipStream_t s, LbvhWorkspace& w, const RtVertex* verts, 
 int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const rtd::InstShade* shade, const rtd::InstRec* insts, u32 n);
 // builds the hierarchy over w.boxes[0..n); nodes_out has max(1, n-1) entries; perm_out[n] = sorted -> original.
 // builder: 0 = Karras LBVH hierarchy, 1 = PLOC agglomerative clustering (pw required)
-int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, int builder, u32 n, int leaf_max, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
+// sah_tri: cost of one triangle test relative to one two-child node step in the surface-area heuristic
+int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
 // TriRec array in leaf order
 int lbvh_write_trirecs(hipStream_t s, const u32* perm, const RtVertex* verts, const uint16_t* indices,
                        const u32* tri_geometry, const rtd::GeomRec* geoms, u32 n_tris, rtd::TriRec* out);

@@ -19,7 +19,6 @@ static constexpr int PLOC_RADIUS = 8;
 static inline dim3 grid_for(u32 n, int bt = BT) { return dim3((n + bt - 1) / bt); }
 
 #define RT_SAH_NODE 1.0f
-#define RT_SAH_TRI  1.3f
 
 RT_DEV float ploc_half_area(const Aabb& b) {
     float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
@@ -111,7 +110,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_ploc_scan_sums(unsigned long lon
 
 __global__ void k_ploc_apply(const int* __restrict__ cid, const Aabb* __restrict__ cbox, const int* __restrict__ nn, u32 m,
                              const unsigned long long* __restrict__ excl, const unsigned long long* __restrict__ sums, u32 node_base,
-                             int leaf_max, int* __restrict__ cid_out, Aabb* __restrict__ cbox_out, BuildNode* __restrict__ bn,
+                             int leaf_max, u32 n_total, float sah_tri, int* __restrict__ cid_out, Aabb* __restrict__ cbox_out, BuildNode* __restrict__ bn,
                              int* __restrict__ leaf_parent, Aabb* __restrict__ node_boxes, u32* __restrict__ size, int* __restrict__ depth,
                              float* __restrict__ cost, u32* __restrict__ collapsed) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,14 +127,14 @@ __global__ void k_ploc_apply(const int* __restrict__ cid, const Aabb* __restrict
     BuildNode nd; nd.left = l; nd.right = r; nd.first = 0; nd.last = 0; nd.parent = -1;
     bn[k] = nd;
     u32 sl = 1, sr = 1; int dl = 0, dr = 0; float cl, cr;
-    if (l < 0) { leaf_parent[~l] = (int) k; cl = RT_SAH_TRI * ploc_half_area(bl); } else { bn[l].parent = (int) k; sl = size[l]; dl = depth[l]; cl = cost[l]; }
-    if (r < 0) { leaf_parent[~r] = (int) k; cr = RT_SAH_TRI * ploc_half_area(br); } else { bn[r].parent = (int) k; sr = size[r]; dr = depth[r]; cr = cost[r]; }
+    if (l < 0) { leaf_parent[~l] = (int) k; cl = sah_tri * ploc_half_area(bl); } else { bn[l].parent = (int) k; sl = size[l]; dl = depth[l]; cl = cost[l]; }
+    if (r < 0) { leaf_parent[~r] = (int) k; cr = sah_tri * ploc_half_area(br); } else { bn[r].parent = (int) k; sr = size[r]; dr = depth[r]; cr = cost[r]; }
     node_boxes[k] = b;
     size[k] = sl + sr;
     depth[k] = 1 + (dl > dr ? dl : dr);
     float a = ploc_half_area(b);
-    float split_cost = RT_SAH_NODE * a + cl + cr, leaf_cost = RT_SAH_TRI * (float) (sl + sr) * a;
-    bool col = (int) (sl + sr) <= leaf_max && leaf_cost <= split_cost;
+    float split_cost = RT_SAH_NODE * a + cl + cr, leaf_cost = sah_tri * (float) (sl + sr) * a;
+    bool col = (int) (sl + sr) <= leaf_max && leaf_cost <= split_cost && sl + sr < n_total; // the root stays a node
     collapsed[k] = col ? 1u : 0u;
     cost[k] = col ? leaf_cost : split_cost;
     cid_out[pos] = (int) k;
@@ -214,7 +213,7 @@ void ploc_workspace_free(PlocWorkspace& w) {
 }
 
 // topology + boxes + leaf order over the n Morton-sorted primitives (w.vals = sorted -> original, w.boxes = original order)
-int ploc_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace& pw, u32 n, int leaf_max, bool tlas, BvhNode* nodes_out, u32* perm_out) {
+int ploc_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace& pw, u32 n, int leaf_max, float sah_tri, bool tlas, BvhNode* nodes_out, u32* perm_out) {
     int rc = ploc_workspace_reserve(pw, n);
     if (rc != RT_OK) return rc;
     hipLaunchKernelGGL(k_ploc_init, grid_for(n), dim3(BT), 0, s, w.boxes, w.vals, n, pw.cid[0], pw.cbox[0]);
@@ -227,7 +226,7 @@ int ploc_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace& pw, u32 n, int le
         hipLaunchKernelGGL(k_ploc_scan_block, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, pw.nn, m, pw.excl, pw.sums);
         hipLaunchKernelGGL(k_ploc_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, pw.sums, nblocks, pw.totals);
         hipLaunchKernelGGL(k_ploc_apply, grid_for(m), dim3(BT), 0, s, pw.cid[cur], pw.cbox[cur], pw.nn, m, pw.excl, pw.sums, node_base,
-                           leaf_max, pw.cid[cur ^ 1], pw.cbox[cur ^ 1], w.build_nodes, w.leaf_parent, w.node_boxes, w.flags, w.depth,
+                           leaf_max, n, sah_tri, pw.cid[cur ^ 1], pw.cbox[cur ^ 1], w.build_nodes, w.leaf_parent, w.node_boxes, w.flags, w.depth,
                            w.cost, w.collapsed);
         u32 totals[2];
         RT_HIP(hipMemcpyAsync(totals, pw.totals, sizeof totals, hipMemcpyDeviceToHost, s));

@@ -3,6 +3,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd import api, scenes, distributed, _abi
+print('RT_SAH_TRI', os.environ.get('RT_SAH_TRI'), 'RT_BVH_BUILDER', os.environ.get('RT_BVH_BUILDER'))
 for name, sc in [("c2", scenes.bunny(1920, 1080, 1, 1)), ("c3", scenes.cornell(1920, 1080, 2, 4)), ("c4", scenes.cornell_bunny(1920, 1080, 1, 4))]:
     rt = api.Raytracer(0); sc.setup(rt, _abi.RT_FLAG_COUNT_TRAVERSAL)
     rt.reset_stats()
