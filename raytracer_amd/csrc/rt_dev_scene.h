@@ -59,8 +59,8 @@ RT_DEV bool first_active_lane() {
 
 // parameters of the (non-spec, conservative) ray/box test for one level
 struct BoxRay {
-    float idx, idy, idz;   // 1 / d
-    float ox, oy, oz;      // -o / d
+    float idx, idy, idz;   // 1 / d  (+-inf for a zero component: the slab then only says inside / outside)
+    float ox, oy, oz;      // origin
     float pad;             // absolute padding in t
 };
 
@@ -72,30 +72,30 @@ RT_DEV float fast_rcp(float x) {
 #endif
 }
 
+// Slab distances are (plane - origin) * (1/d): the subtraction is exact to half an ulp of its result, so a relative
+// pad covers the rounding of the box test itself, whatever the size of 1/d.  The absolute pad covers the rounding of
+// the *triangle* test, whose t is a quotient of sums of terms of size (extent + |o|) / max|d| (S4): two hits closer
+// together than that may order differently than their boxes do.
 RT_DEV BoxRay make_box_ray(f3 o, f3 d, float bound) {
     BoxRay b;
     b.idx = fast_rcp(d.x); b.idy = fast_rcp(d.y); b.idz = fast_rcp(d.z);
-    b.ox = -o.x * b.idx; b.oy = -o.y * b.idy; b.oz = -o.z * b.idz;
-    float px = (fabsf(o.x) + bound) * fabsf(b.idx);
-    float py = (fabsf(o.y) + bound) * fabsf(b.idy);
-    float pz = (fabsf(o.z) + bound) * fabsf(b.idz);
-    float pm = fminf(fminf(px, py), pz); // NaN/inf tolerant: only finite, relevant axes bound the interval
-    // a slab whose |1/d| is huge contributes an interval that is either empty or contains every t of interest;
-    // padding by the largest finite term keeps the test conservative for the other two
-    float pmax = fmaxf(fmaxf(px < 3.0e38f ? px : pm, py < 3.0e38f ? py : pm), pz < 3.0e38f ? pz : pm);
-    b.pad = pmax * 1.0e-6f;
+    b.ox = o.x; b.oy = o.y; b.oz = o.z;
+    float omax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+    float imin = fminf(fminf(fabsf(b.idx), fabsf(b.idy)), fabsf(b.idz)); // 1 / largest |component of d|
+    b.pad = 4.0e-6f * (bound + omax) * imin;
     return b;
 }
 
-// returns entry distance; hit iff entry <= exit
+// returns entry distance; hit iff entry <= exit.  NaNs (0 * inf: origin exactly on a plane of a slab the ray is
+// parallel to) are dropped by min/max, which keeps the test conservative.
 RT_DEV bool box_test(const BoxRay& r, const float* lo, const float* hi, float tmin, float tmax, float& entry) {
-    float t0x = __builtin_fmaf(lo[0], r.idx, r.ox), t1x = __builtin_fmaf(hi[0], r.idx, r.ox);
-    float t0y = __builtin_fmaf(lo[1], r.idy, r.oy), t1y = __builtin_fmaf(hi[1], r.idy, r.oy);
-    float t0z = __builtin_fmaf(lo[2], r.idz, r.oz), t1z = __builtin_fmaf(hi[2], r.idz, r.oz);
+    float t0x = (lo[0] - r.ox) * r.idx, t1x = (hi[0] - r.ox) * r.idx;
+    float t0y = (lo[1] - r.oy) * r.idy, t1y = (hi[1] - r.oy) * r.idy;
+    float t0z = (lo[2] - r.oz) * r.idz, t1z = (hi[2] - r.oz) * r.idz;
     float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
     float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-    tn = tn - r.pad - fabsf(tn) * 2.0e-6f;
-    tf = tf + r.pad + fabsf(tf) * 2.0e-6f;
+    tn = __builtin_fmaf(fabsf(tn), -2.0e-6f, tn - r.pad);
+    tf = __builtin_fmaf(fabsf(tf), 2.0e-6f, tf + r.pad);
     entry = tn;
     return fmaxf(tn, tmin) <= fminf(tf, tmax);
 }
@@ -117,6 +117,10 @@ RT_DEV void trace_closest(const SceneView& sc, f3 o, f3 d, float tmin, float tma
                           TraverseCounters& cnt) {
     best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.inst = -1; best.tri = -1; best.prim_global = 0;
     bool have_hit = false;
+    // a NaN in the ray makes every triangle test fail (S4 compares with NaN are false): the answer is a miss, and
+    // it must not cost a walk through the whole tree (NaN box tests pass conservatively).  Such rays do occur:
+    // a shading normal perpendicular to the ray is scaled by sign(0) = 0 (raytracing.hlsl:64-65).
+    if (!(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z)) { best.t = inf_f32(); return; }
 
     const RT_GLOBAL BvhNode* const tlas_nodes = (const RT_GLOBAL BvhNode*) sc.tlas_nodes;
     const RT_GLOBAL InstRec* const insts = (const RT_GLOBAL InstRec*) sc.insts;

@@ -84,3 +84,19 @@ def test_tile_split_sums_to_the_full_image(oracle_mod):
     for rt in [full] + parts:
         rt.close()
     cpu.close()
+
+
+def test_c5_instanced_field_small(oracle_mod):
+    """C5 at reduced size: 300 rotated/scaled bunny instances (284k triangles) through the two-level BVH"""
+    scene = scenes.bunny_field(160, 90, spp=1, bounces=2, grid=20, count=300)
+    _check_scene(scene, oracle_mod, frames=2, brute_force=False)
+
+
+def test_many_instances_of_tiny_blas(oracle_mod):
+    """TLAS-heavy case: 1500 instances of the 12-triangle cube, brute-force oracle"""
+    from raytracer_amd import host
+    s = scenes.debug_cube(96, 96, spp=1, bounces=2)
+    rs = np.random.RandomState(11)
+    s.instances = [(host.affine_transform(float(rs.uniform(0.02, 0.06)), float(rs.uniform(0, 6.28)),
+                                          tuple(rs.uniform(-0.7, 0.7, 3))), 0) for _ in range(1500)] + [s.instances[1]]
+    _check_scene(s, oracle_mod, frames=1, brute_force=True)
