@@ -82,7 +82,7 @@ struct rt_ctx {
     // BSSRDF tables
     float* d_table[2] = { nullptr, nullptr }; int table_texels[2] = { 0, 0 }; int profile = 0;
     // stats
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed; double traverse_ms = 0; uint64_t traverse_launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed; double traverse_ms = 0; uint64_t traverse_launches = 0, primary_rays = 0;
     double blas_build_ms = 0, tlas_build_ms = 0; uint64_t blas_triangles = 0;
     rt_ctx() { memset(&g, 0, sizeof g); memset(q, 0, sizeof q); memset(&hits, 0, sizeof hits); memset(&ps, 0, sizeof ps); memset(&gq, 0, sizeof gq); }
 };
@@ -172,16 +172,28 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.bssrdf_table = c->d_table[c->profile]; a.bssrdf_texels = c->table_texels[c->profile];
 }
 
-int timed_traverse(rt_ctx* c, const PassArgs& a, u32 inq) {
+// pixels of this rank's tiles that lie inside the image
+uint64_t local_pixel_count(const PassArgs& a) {
+    uint64_t n = 0;
+    for (u32 k = 0; k < a.n_local_tiles; k++) {
+        u32 tile = k * a.tile_world + a.tile_rank, tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+        u32 w = std::min(32u, a.width - tx * 32u), h = std::min(32u, a.height - ty * 32u);
+        n += (uint64_t) w * h;
+    }
+    return n;
+}
+
+int timed_traverse(rt_ctx* c, const PassArgs& a, u32 inq, bool primary, u32 sample_index) {
     bool timing = (c->flags & RT_FLAG_TIME_KERNELS) != 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) {
         RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
         RT_HIP(hipEventRecord(e0, c->stream));
     }
-    int rc = launch_traverse(c->stream, a, inq, (c->flags & RT_FLAG_COUNT_TRAVERSAL) != 0, c->traverse_variant);
+    int rc = launch_traverse(c->stream, a, inq, (c->flags & RT_FLAG_COUNT_TRAVERSAL) != 0, c->traverse_variant, primary, sample_index);
     if (timing) { RT_HIP(hipEventRecord(e1, c->stream)); c->timed.emplace_back(e0, e1); }
     c->traverse_launches++;
+    if (primary) c->primary_rays += local_pixel_count(a); // bounce-0 rays are not queued, so the device does not count them
     return rc;
 }
 
@@ -212,16 +224,21 @@ int run_pass(rt_ctx* c, bool probe) {
         int rc = launch_fill_capture(c->stream, a); if (rc) return rc;
     }
     bool gather = a.gather_enabled != 0;
+    // camera pass: no ray-generation kernel (bounce 0 derives rays from pixels), and unless the gather kernel can add
+    // emission after a path's last shade, no resolve kernel either (finished paths resolve their pixel in k_shade)
+    bool fused = !probe && !gather;
     for (u32 s = 0; s < c->g.samples_per_pixel; s++) {
-        int rc = probe ? launch_probe_raygen(c->stream, a, s) : launch_camera_raygen(c->stream, a, s);
-        if (rc) return rc;
+        int rc = RT_OK;
+        if (probe) { rc = launch_probe_raygen(c->stream, a, s); if (rc) return rc; }
         for (u32 b = 0; b <= c->g.bounces_per_sample; b++) {
-            rc = timed_traverse(c, a, b & 1u); if (rc) return rc;
-            rc = launch_shade(c->stream, a, b & 1u, b, s); if (rc) return rc;
+            bool primary = !probe && b == 0;
+            rc = timed_traverse(c, a, b & 1u, primary, s); if (rc) return rc;
+            rc = launch_shade(c->stream, a, b & 1u, b, s, primary, fused); if (rc) return rc;
             if (gather && (int) b <= c->g.translucent_emission_bounces) { rc = launch_gather(c->stream, a); if (rc) return rc; }
         }
     }
-    return probe ? launch_probe_resolve(c->stream, a) : launch_camera_resolve(c->stream, a);
+    if (probe) return launch_probe_resolve(c->stream, a);
+    return fused ? RT_OK : launch_camera_resolve(c->stream, a);
 }
 
 float triangle_area(const float* a, const float* b, const float* c) { // geometry.cpp:21-25
@@ -666,7 +683,7 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
     DeviceStats ds;
     RT_HIP(hipMemcpy(&ds, c->d_stats, sizeof ds, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
-    out->rays_camera = ds.rays_camera; out->rays_probe = ds.rays_probe; out->gather_pairs = ds.gather_pairs;
+    out->rays_camera = ds.rays_camera + c->primary_rays; out->rays_probe = ds.rays_probe; out->gather_pairs = ds.gather_pairs;
     out->nodes_visited = ds.nodes; out->tris_tested = ds.tris; out->instances_entered = ds.insts;
     out->wave_node_steps = ds.node_trips; out->wave_tri_steps = ds.tri_trips; out->wave_instance_steps = ds.inst_trips;
     out->traverse_launches = c->traverse_launches; out->traverse_ms = c->traverse_ms;
@@ -679,7 +696,7 @@ int rt_reset_stats(rt_ctx* c) {
     RT_HIP(hipStreamSynchronize(c->stream));
     int rc = drain_timers(c); if (rc) return rc;
     RT_HIP(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
-    c->traverse_ms = 0; c->traverse_launches = 0;
+    c->traverse_ms = 0; c->traverse_launches = 0; c->primary_rays = 0;
     return RT_OK;
 }
 

@@ -122,10 +122,11 @@ struct PassArgs {
     int bssrdf_texels;
 };
 
-int launch_camera_raygen(hipStream_t s, const PassArgs& a, u32 sample_index);
 int launch_probe_raygen(hipStream_t s, const PassArgs& a, u32 sample_index);
-int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, int variant);
-int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index);
+// primary: bounce 0 of the camera pass (rays derived from pixels; in_queue unused)
+int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, int variant, bool primary, u32 sample_index);
+// fused: finished camera paths resolve their pixel in the shade kernel (no launch_camera_resolve afterwards)
+int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index, bool primary, bool fused);
 int launch_gather(hipStream_t s, const PassArgs& a);
 int launch_camera_resolve(hipStream_t s, const PassArgs& a);
 int launch_probe_resolve(hipStream_t s, const PassArgs& a);

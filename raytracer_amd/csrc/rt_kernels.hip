@@ -1,6 +1,6 @@
 // rt_kernels.hip -- the wavefront path-tracing pipeline for gfx950.
 //
-//   camera_rgen      (raytracing.hlsl:128-163)  ->  k_camera_raygen / k_camera_resolve
+//   camera_rgen      (raytracing.hlsl:128-163)  ->  folded into bounce 0 of k_traverse / k_shade (+ k_camera_resolve)
 //   translucent_rgen (raytracing.hlsl:224-265)  ->  k_probe_raygen  / k_probe_resolve
 //   trace_path_sample loop (raytracing.hlsl:92-126) -> per bounce: k_traverse -> k_shade [-> k_gather]
 //   TraceRay (driver)                            ->  k_traverse: one ray per lane, two-level BVH2, per-lane stack in LDS
@@ -75,49 +75,16 @@ RT_DEV bool thread_pixel(const PassArgs& a, u32 t, u32& px, u32& py) {
     return px < a.width && py < a.height;
 }
 
-__global__ __launch_bounds__(SEG) void k_camera_raygen(PassArgs a, u32 sample_index) {
-    __shared__ u32 s_wave[SEG / 64];
-    u32 t = blockIdx.x * SEG + threadIdx.x;
-    u32 px = 0, py = 0;
-    bool active = thread_pixel(a, t, px, py);
-    u32 pixel = py * a.width + px;
-    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
-    if (active) {
-        u32 rng;
-        if (sample_index == 0) {
-            rng = hash_u3(px, py, a.g.frame_rng * (u32) (a.g.accumulator_count != 0)); // raytracing.hlsl:130
-            a.ps.sum_x[pixel] = 0.0f; a.ps.sum_y[pixel] = 0.0f; a.ps.sum_z[pixel] = 0.0f; a.ps.sum_a[pixel] = 0.0f;
-        } else {
-            rng = a.ps.rng[pixel];
-            a.ps.sum_x[pixel] += a.ps.rad_x[pixel]; a.ps.sum_y[pixel] += a.ps.rad_y[pixel];
-            a.ps.sum_z[pixel] += a.ps.rad_z[pixel]; a.ps.sum_a[pixel] += a.ps.alpha[pixel];
-        }
-        camera_ray(a.g, px, py, a.width, a.height, rng, o, d);
-        a.ps.rng[pixel] = rng;
-        a.ps.thr_x[pixel] = 1.0f; a.ps.thr_y[pixel] = 1.0f; a.ps.thr_z[pixel] = 1.0f;
-        a.ps.rad_x[pixel] = 0.0f; a.ps.rad_y[pixel] = 0.0f; a.ps.rad_z[pixel] = 0.0f; a.ps.alpha[pixel] = 1.0f;
-    }
-    u32 total;
-    u32 slot = blockIdx.x * SEG + block_rank(active, s_wave, total);
-    if (active) {
-        const RayQueue& q = a.q[0];
-        q.ox[slot] = o.x; q.oy[slot] = o.y; q.oz[slot] = o.z;
-        q.dx[slot] = d.x; q.dy[slot] = d.y; q.dz[slot] = d.z;
-        q.path[slot] = pixel;
-    }
-    if (threadIdx.x == 0) a.seg_count[0][blockIdx.x] = total;
+// primary ray of a pixel for sample `sample_index` of this dispatch (raytracing.hlsl:130,141-149).  There is no camera
+// ray-generation kernel: the bounce-0 traverse and shade kernels both derive the ray from the pixel (a hash, two draws
+// and a 3x3 transform), which is cheaper than a 28-byte round trip through the ray queue.
+RT_DEV void primary_ray(const PassArgs& a, u32 px, u32 py, u32 pixel, u32 sample_index, u32& rng, f3& o, f3& d) {
+    rng = sample_index == 0 ? hash_u3(px, py, a.g.frame_rng * (u32) (a.g.accumulator_count != 0)) : a.ps.rng[pixel];
+    camera_ray(a.g, px, py, a.width, a.height, rng, o, d);
 }
 
-__global__ __launch_bounds__(BT) void k_camera_resolve(PassArgs a) {
-    u32 t = blockIdx.x * BT + threadIdx.x;
-    u32 px, py;
-    if (!thread_pixel(a, t, px, py)) return;
-    u32 pixel = py * a.width + px;
-    float acc[4];
-    acc[0] = a.ps.sum_x[pixel] + a.ps.rad_x[pixel];
-    acc[1] = a.ps.sum_y[pixel] + a.ps.rad_y[pixel];
-    acc[2] = a.ps.sum_z[pixel] + a.ps.rad_z[pixel];
-    acc[3] = a.ps.sum_a[pixel] + a.ps.alpha[pixel];
+// the tail of camera_rgen (raytracing.hlsl:153-161): `tot` = sum of the dispatch's samples of one pixel
+RT_DEV void resolve_pixel(const PassArgs& a, u32 pixel, float* tot /* [4] */) {
     float spp = (float) a.g.samples_per_pixel;
     float4 prev = make_float4(0, 0, 0, 0);
     if (a.g.accumulator_count != 0) prev = ((const float4*) a.accumulator)[pixel];
@@ -125,12 +92,26 @@ __global__ __launch_bounds__(BT) void k_camera_resolve(PassArgs a) {
     float denom = (float) (a.g.accumulator_count + 1u);
     unsigned char rt[4];
     for (int k = 0; k < 4; k++) {
-        acc[k] = acc[k] / spp;                                   // raytracing.hlsl:153
-        if (a.g.accumulator_count != 0) acc[k] = acc[k] + pv[k]; // :155-158
-        rt[k] = to_unorm8(sqrtf(acc[k] / denom));                // :161
+        tot[k] = tot[k] / spp;                                   // raytracing.hlsl:153
+        if (a.g.accumulator_count != 0) tot[k] = tot[k] + pv[k]; // :155-158
+        rt[k] = to_unorm8(sqrtf(tot[k] / denom));                // :161
     }
-    ((float4*) a.accumulator)[pixel] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    ((float4*) a.accumulator)[pixel] = make_float4(tot[0], tot[1], tot[2], tot[3]);
     ((uchar4*) a.render_target)[pixel] = make_uchar4(rt[0], rt[1], rt[2], rt[3]);
+}
+
+// separate resolve pass: only when the BSSRDF gather kernel may still add emission after a path's last shade
+__global__ __launch_bounds__(BT) void k_camera_resolve(PassArgs a) {
+    u32 t = blockIdx.x * BT + threadIdx.x;
+    u32 px, py;
+    if (!thread_pixel(a, t, px, py)) return;
+    u32 pixel = py * a.width + px;
+    float tot[4];
+    tot[0] = a.ps.sum_x[pixel] + a.ps.rad_x[pixel];
+    tot[1] = a.ps.sum_y[pixel] + a.ps.rad_y[pixel];
+    tot[2] = a.ps.sum_z[pixel] + a.ps.rad_z[pixel];
+    tot[3] = a.ps.sum_a[pixel] + a.ps.alpha[pixel];
+    resolve_pixel(a, pixel, tot);
 }
 
 // re-derives the render target from an accumulator that already holds `accumulator_count` frames
@@ -205,24 +186,35 @@ __global__ __launch_bounds__(BT) void k_probe_resolve(PassArgs a) {
 }
 
 // ---- TraceRay ---------------------------------------------------------------------------------------------------
-template <bool COUNT, int MODE, int WAVES_PER_SIMD>
-__global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq) {
+// PRIMARY: bounce 0 of the camera pass; lane t traces the primary ray of thread_pixel(t), the hit goes to slot t.
+template <bool COUNT, int MODE, int WAVES_PER_SIMD, bool PRIMARY>
+__global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq, u32 sample_index) {
     __shared__ int smem[LDS_STACK_DEPTH * TRAVERSE_WAVE];
-    const u32 seg = blockIdx.x / (SEG / TRAVERSE_WAVE);
-    const u32 idx = (blockIdx.x % (SEG / TRAVERSE_WAVE)) * TRAVERSE_WAVE + threadIdx.x;
-    const u32 n = a.seg_count[inq][seg];
-    if (blockIdx.x == 0) { // ray statistics: one wave sums the segment counts of this launch
-        u32 sum = 0;
-        for (u32 k = threadIdx.x; k < a.n_segments; k += TRAVERSE_WAVE) sum += a.seg_count[inq][k];
-        sum = wave_sum(sum);
-        if (threadIdx.x == 0) atomicAdd(a.probe ? &a.stats->rays_probe : &a.stats->rays_camera, (unsigned long long) sum);
+    const u32 qi = blockIdx.x * TRAVERSE_WAVE + threadIdx.x;
+    bool active;
+    f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
+    if (PRIMARY) {
+        u32 px, py;
+        active = thread_pixel(a, qi, px, py);
+        if (active) { u32 rng; primary_ray(a, px, py, py * a.width + px, sample_index, rng, o, d); }
+    } else {
+        const u32 seg = blockIdx.x / (SEG / TRAVERSE_WAVE);
+        const u32 idx = (blockIdx.x % (SEG / TRAVERSE_WAVE)) * TRAVERSE_WAVE + threadIdx.x;
+        if (blockIdx.x == 0) { // ray statistics: one wave sums the segment counts of this launch
+            u32 sum = 0;
+            for (u32 k = threadIdx.x; k < a.n_segments; k += TRAVERSE_WAVE) sum += a.seg_count[inq][k];
+            sum = wave_sum(sum);
+            if (threadIdx.x == 0) atomicAdd(a.probe ? &a.stats->rays_probe : &a.stats->rays_camera, (unsigned long long) sum);
+        }
+        active = idx < a.seg_count[inq][seg];
+        if (active) {
+            const RayQueue& q = a.q[inq];
+            o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
+            d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
+        }
     }
-    const u32 qi = seg * SEG + idx;
     TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
-    if (idx < n) {
-        const RayQueue& q = a.q[inq];
-        f3 o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
-        f3 d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
+    if (active) {
         LaneStack st; st.lds = (RT_LDS int*) &smem[threadIdx.x]; st.spill = (RT_GLOBAL int*) (a.stack_spill + qi);
         st.spill_stride = a.n_paths; st.sp = 0;
         HitOut h;
@@ -246,38 +238,76 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
 }
 
 // ---- hit / miss shaders + the tail of the trace_path_sample loop body (raytracing.hlsl:113-119) ------------------
+// PRIMARY: bounce 0 of the camera pass (thread t shades pixel thread_pixel(t); the path state starts here).
+// FUSED: a path that ends here also finishes its pixel (sample sum, accumulate, tone-map) -- no resolve kernel, and no
+// radiance / alpha / sum traffic for finished paths.  Not usable while the gather kernel may add emission afterwards.
+template <bool PRIMARY, bool FUSED>
 __global__ __launch_bounds__(SEG) void k_shade(PassArgs a, u32 inq, u32 bounce, u32 sample_index) {
     __shared__ u32 s_wave[SEG / 64];
-    const u32 n = a.seg_count[inq][blockIdx.x];
     const u32 qi = blockIdx.x * SEG + threadIdx.x;
-    bool active = threadIdx.x < n;
-    bool cont = false, gather = false;
-    u32 path = 0;
+    bool active, cont = false, gather = false;
+    u32 path = 0, rng = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
     f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
     ShadeOut r;
-    f3 thr_prev = mk3(0, 0, 0);
+    f3 thr_prev = mk3(1.0f, 1.0f, 1.0f), rad = mk3(0.0f, 0.0f, 0.0f);
+    if (PRIMARY) {
+        u32 px = 0, py = 0;
+        active = thread_pixel(a, qi, px, py);
+        path = py * a.width + px;
+        if (active) {
+            if (!FUSED) { // per-dispatch sample sum (raytracing.hlsl:139-151), resolved by k_camera_resolve
+                if (sample_index == 0) {
+                    a.ps.sum_x[path] = 0.0f; a.ps.sum_y[path] = 0.0f; a.ps.sum_z[path] = 0.0f; a.ps.sum_a[path] = 0.0f;
+                } else {
+                    a.ps.sum_x[path] += a.ps.rad_x[path]; a.ps.sum_y[path] += a.ps.rad_y[path];
+                    a.ps.sum_z[path] += a.ps.rad_z[path]; a.ps.sum_a[path] += a.ps.alpha[path];
+                }
+            }
+            primary_ray(a, px, py, path, sample_index, rng, o, d);
+        }
+    } else {
+        active = threadIdx.x < a.seg_count[inq][blockIdx.x];
+        if (active) {
+            const RayQueue& q = a.q[inq];
+            path = q.path[qi];
+            o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
+            d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
+            rng = a.ps.rng[path];
+            thr_prev = mk3(a.ps.thr_x[path], a.ps.thr_y[path], a.ps.thr_z[path]);
+            rad = mk3(a.ps.rad_x[path], a.ps.rad_y[path], a.ps.rad_z[path]);
+        }
+    }
     if (active) {
-        const RayQueue& q = a.q[inq];
-        path = q.path[qi];
-        f3 o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
-        f3 d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
         HitOut h;
         h.t = a.hits.t[qi]; h.u = a.hits.u[qi]; h.v = a.hits.v[qi]; h.inst = a.hits.inst[qi]; h.tri = a.hits.tri[qi];
         h.prim_global = 0;
-        u32 rng = a.ps.rng[path];
         float payload_t = a.probe ? inf_f32() : (float) bounce; // raytracing.hlsl:102-107
         shade_ray(a.shade, a.g, a.fudge, o, d, h, payload_t, rng, r);
-        thr_prev = mk3(a.ps.thr_x[path], a.ps.thr_y[path], a.ps.thr_z[path]);
-        f3 rad = mk3(a.ps.rad_x[path], a.ps.rad_y[path], a.ps.rad_z[path]);
         rad = rad + r.emission * thr_prev;            // :113
         f3 thr = thr_prev * r.reflectance;            // :114
         bool alive = any3(r.reflectance);             // :116
         cont = alive && bounce < a.g.bounces_per_sample;
         gather = r.gather;
-        a.ps.rng[path] = rng;
-        a.ps.rad_x[path] = rad.x; a.ps.rad_y[path] = rad.y; a.ps.rad_z[path] = rad.z;
-        a.ps.thr_x[path] = thr.x; a.ps.thr_y[path] = thr.y; a.ps.thr_z[path] = thr.z;
-        if (bounce == 0 && h.inst < 0) a.ps.alpha[path] = 0.0f; // result.a, :122
+        const bool missed_primary = bounce == 0 && h.inst < 0; // result.a = 0, :122
+        if (!FUSED || cont) {
+            a.ps.rng[path] = rng;
+            a.ps.rad_x[path] = rad.x; a.ps.rad_y[path] = rad.y; a.ps.rad_z[path] = rad.z;
+            a.ps.thr_x[path] = thr.x; a.ps.thr_y[path] = thr.y; a.ps.thr_z[path] = thr.z;
+            if (!FUSED) {
+                if (PRIMARY) a.ps.alpha[path] = missed_primary ? 0.0f : 1.0f;
+                else if (missed_primary) a.ps.alpha[path] = 0.0f;
+            }
+        } else {
+            // the sample is complete: fold it into the pixel (same order of additions as the separate resolve pass)
+            float smp[4] = { rad.x, rad.y, rad.z, missed_primary ? 0.0f : 1.0f }, tot[4];
+            float* const sum[4] = { a.ps.sum_x, a.ps.sum_y, a.ps.sum_z, a.ps.sum_a };
+            for (int k = 0; k < 4; k++) tot[k] = (sample_index == 0 ? 0.0f : sum[k][path]) + smp[k];
+            if (sample_index + 1u < a.g.samples_per_pixel) {
+                a.ps.rng[path] = rng; // the next sample of this pixel continues the stream (raytracing.hlsl:130,141)
+                for (int k = 0; k < 4; k++) sum[k][path] = tot[k];
+            } else resolve_pixel(a, path, tot);
+        }
         if (alive) { no = o + r.t * d; nd = r.scatter; }       // :118-119
         if (a.probe && !cont) {
             // ray.Direction as trace_path_sample leaves it: the last traced direction after a break,
@@ -366,13 +396,6 @@ __global__ __launch_bounds__(BT) void k_fill_capture(RtHit* capture, size_t n) {
 // ---- launchers ---------------------------------------------------------------------------------------------------
 static inline dim3 blocks(size_t n, int bt) { return dim3((unsigned) ((n + bt - 1) / bt)); }
 
-int launch_camera_raygen(hipStream_t s, const PassArgs& a, u32 sample_index) {
-    size_t threads = (size_t) a.n_local_tiles * 1024;
-    if (!threads) return RT_OK;
-    hipLaunchKernelGGL(k_camera_raygen, dim3(a.n_segments), dim3(SEG), 0, s, a, sample_index);
-    RT_HIP(hipGetLastError());
-    return RT_OK;
-}
 int launch_probe_raygen(hipStream_t s, const PassArgs& a, u32 sample_index) {
     if (!a.n_points) return RT_OK;
     hipLaunchKernelGGL(k_probe_raygen, dim3(a.n_segments), dim3(SEG), 0, s, a, sample_index);
@@ -380,26 +403,31 @@ int launch_probe_raygen(hipStream_t s, const PassArgs& a, u32 sample_index) {
     return RT_OK;
 }
 static size_t pass_paths(const PassArgs& a) { return (size_t) a.n_segments * SEG; }
-int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, int variant) {
+int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, int variant, bool primary, u32 sample_index) {
     size_t n = pass_paths(a);
     if (!n) return RT_OK;
     dim3 grid = blocks(n, TRAVERSE_WAVE), block(TRAVERSE_WAVE);
-    if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, 1>), grid, block, 0, s, a, in_queue);
-    else switch (variant) {
-        case 0: hipLaunchKernelGGL((k_traverse<false, 0, 1>), grid, block, 0, s, a, in_queue); break;
-        case 2: hipLaunchKernelGGL((k_traverse<false, 1, 6>), grid, block, 0, s, a, in_queue); break;
-        case 3: hipLaunchKernelGGL((k_traverse<false, 1, 8>), grid, block, 0, s, a, in_queue); break;
-        case 4: hipLaunchKernelGGL((k_traverse<false, 0, 8>), grid, block, 0, s, a, in_queue); break;
-        case 5: hipLaunchKernelGGL((k_traverse<false, 1, 1>), grid, block, 0, s, a, in_queue); break;
-        default: hipLaunchKernelGGL((k_traverse<false, 1, 5>), grid, block, 0, s, a, in_queue); break;
+    // variant 0 = one node or leaf per loop trip ("if-if"); default = "while-while" (rt_dev_scene.h)
+    if (primary) {
+        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, 1, true>), grid, block, 0, s, a, in_queue, sample_index);
+        else if (variant == 0) hipLaunchKernelGGL((k_traverse<false, 0, 5, true>), grid, block, 0, s, a, in_queue, sample_index);
+        else hipLaunchKernelGGL((k_traverse<false, 1, 5, true>), grid, block, 0, s, a, in_queue, sample_index);
+    } else {
+        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, 1, false>), grid, block, 0, s, a, in_queue, sample_index);
+        else if (variant == 0) hipLaunchKernelGGL((k_traverse<false, 0, 5, false>), grid, block, 0, s, a, in_queue, sample_index);
+        else hipLaunchKernelGGL((k_traverse<false, 1, 5, false>), grid, block, 0, s, a, in_queue, sample_index);
     }
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
-int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index) {
+int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index, bool primary, bool fused) {
     size_t n = pass_paths(a);
     if (!n) return RT_OK;
-    hipLaunchKernelGGL(k_shade, dim3(a.n_segments), dim3(SEG), 0, s, a, in_queue, bounce, sample_index);
+    dim3 grid(a.n_segments), block(SEG);
+    if (primary && fused) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, s, a, in_queue, bounce, sample_index);
+    else if (primary) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, s, a, in_queue, bounce, sample_index);
+    else if (fused) hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, s, a, in_queue, bounce, sample_index);
+    else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, s, a, in_queue, bounce, sample_index);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
