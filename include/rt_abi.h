@@ -129,6 +129,7 @@ typedef struct RtStats {
     uint64_t wave_node_steps;      /* with RT_FLAG_COUNT_TRAVERSAL: node / triangle / instance steps counted once per   */
     uint64_t wave_tri_steps;       /* 64-lane wave; lane steps / (64 * wave steps) = SIMD efficiency of the traversal    */
     uint64_t wave_instance_steps;
+    uint64_t max_ray_steps;        /* RT_FLAG_COUNT_TRAVERSAL: most node + triangle + instance steps taken by one ray */
 } RtStats;
 
 /* rt_set_flags bits */

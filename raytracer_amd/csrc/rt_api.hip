@@ -34,7 +34,7 @@ struct TranslucentMesh { // raytracing.cpp:49-53 + BluenoisePreprocess (bluenois
 
 struct Blas {
     RtVertex* d_verts = nullptr; uint16_t* d_indices = nullptr; GeomRec* d_geoms = nullptr; u32* d_tri_geometry = nullptr;
-    BvhNode* d_nodes = nullptr; TriRec* d_tris = nullptr; u32* d_perm = nullptr;
+    BvhNode* d_nodes = nullptr; TriRec* d_tris = nullptr; /* inside the d_nodes allocation */ u32* d_perm = nullptr; float bound = 0;
     std::vector<RtVertex> verts; std::vector<uint16_t> indices; std::vector<GeomRec> geoms;
     u32 n_tris = 0; int depth = 0;
     u32 translucent_ids_index = 0, translucent_ids_count = 0;
@@ -74,7 +74,6 @@ struct rt_ctx {
     float* d_accumulator = nullptr; uint8_t* d_render_target = nullptr;
     RtHit* d_capture = nullptr; size_t capture_records = 0; u32 capture_bounces = 0;
     u32 tile_rank = 0, tile_world = 1;
-    int traverse_variant = 1; // RT_TRAVERSE_VARIANT: kernel A/B switch (tuning aid)
     // path buffers
     u32 n_paths = 0; float* d_arena = nullptr;
     RayQueue q[2]; HitBuf hits; PathState ps; GatherQueue gq; int* d_stack_spill = nullptr;
@@ -190,7 +189,7 @@ int timed_traverse(rt_ctx* c, const PassArgs& a, u32 inq, bool primary, u32 samp
         RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
         RT_HIP(hipEventRecord(e0, c->stream));
     }
-    int rc = launch_traverse(c->stream, a, inq, (c->flags & RT_FLAG_COUNT_TRAVERSAL) != 0, c->traverse_variant, primary, sample_index);
+    int rc = launch_traverse(c->stream, a, inq, (c->flags & RT_FLAG_COUNT_TRAVERSAL) != 0, primary, sample_index);
     if (timing) { RT_HIP(hipEventRecord(e1, c->stream)); c->timed.emplace_back(e0, e1); }
     c->traverse_launches++;
     if (primary) c->primary_rays += local_pixel_count(a); // bounce-0 rays are not queued, so the device does not count them
@@ -277,7 +276,6 @@ int rt_create(const int* devices, int n, rt_ctx** out) {
     RT_HIP(hipSetDevice(devices[0]));
     rt_ctx* c = new rt_ctx();
     c->device = devices[0];
-    if (const char* v = getenv("RT_TRAVERSE_VARIANT")) c->traverse_variant = atoi(v);
     if (const char* v = getenv("RT_BVH_BUILDER")) c->bvh_builder = atoi(v);
     if (const char* v = getenv("RT_SAH_TRI")) c->sah_tri = (float) atof(v);
     RT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -295,7 +293,7 @@ void rt_destroy(rt_ctx* c) {
     drain_timers(c);
     for (auto& b : c->blas) {
         dev_free(b.d_verts); dev_free(b.d_indices); dev_free(b.d_geoms); dev_free(b.d_tri_geometry);
-        dev_free(b.d_nodes); dev_free(b.d_tris); dev_free(b.d_perm);
+        dev_free(b.d_nodes); b.d_tris = nullptr; dev_free(b.d_perm);
     }
     for (auto& m : c->translucent_meshes) dev_free(m.d_partial_areas);
     free_sample_points(c);
@@ -409,8 +407,9 @@ int rt_build_blas(rt_ctx* c, const RtGeometry* geometries, int n, rt_blas* out) 
     RT_HIP(hipMalloc(&b.d_indices, b.indices.size() * sizeof(uint16_t)));
     RT_HIP(hipMalloc(&b.d_geoms, b.geoms.size() * sizeof(GeomRec)));
     RT_HIP(hipMalloc(&b.d_tri_geometry, tri_geometry.size() * 4));
-    RT_HIP(hipMalloc(&b.d_nodes, n_nodes * sizeof(BvhNode)));
-    RT_HIP(hipMalloc(&b.d_tris, b.n_tris * sizeof(TriRec)));
+    // nodes and triangles share one allocation: an instance record addresses both with one pointer + a 32-bit offset
+    RT_HIP(hipMalloc(&b.d_nodes, n_nodes * sizeof(BvhNode) + b.n_tris * sizeof(TriRec)));
+    b.d_tris = (TriRec*) (b.d_nodes + n_nodes);
     RT_HIP(hipMalloc(&b.d_perm, b.n_tris * 4));
     RT_HIP(hipMemcpyAsync(b.d_verts, b.verts.data(), b.verts.size() * sizeof(RtVertex), hipMemcpyHostToDevice, c->stream));
     RT_HIP(hipMemcpyAsync(b.d_indices, b.indices.data(), b.indices.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
@@ -428,7 +427,7 @@ int rt_build_blas(rt_ctx* c, const RtGeometry* geometries, int n, rt_blas* out) 
     float ms = 0; RT_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     c->blas_build_ms = ms;
-    b.depth = root.depth;
+    b.depth = root.depth; b.bound = root.bound;
     c->blas_triangles += b.n_tris;
     for (auto& m : new_meshes) { c->translucent_meshes.push_back(m); c->translucent_mean_area.push_back(0.0f); }
     c->blas.push_back(std::move(b));
@@ -463,7 +462,7 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
             c->g.translucent_instance_stride = std::max(c->g.translucent_instance_stride, counts[instances[i].blas]);
         }
         invert_affine(instances[i].transform, rec[i].world_to_object);
-        rec[i].nodes = b.d_nodes; rec[i].tris = b.d_tris;
+        rec[i].nodes = b.d_nodes; rec[i].tris_offset = (u32) ((const char*) b.d_tris - (const char*) b.d_nodes); rec[i].bound = b.bound;
         memcpy(shade[i].object_to_world, instances[i].transform, 64);
         shade[i].vertices = b.d_verts; shade[i].indices = b.d_indices; shade[i].geoms = b.d_geoms; shade[i].tris = b.d_tris;
         shade[i].instance_id = instance_id; shade[i]._pad = 0;
@@ -685,7 +684,7 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
     memset(out, 0, sizeof *out);
     out->rays_camera = ds.rays_camera + c->primary_rays; out->rays_probe = ds.rays_probe; out->gather_pairs = ds.gather_pairs;
     out->nodes_visited = ds.nodes; out->tris_tested = ds.tris; out->instances_entered = ds.insts;
-    out->wave_node_steps = ds.node_trips; out->wave_tri_steps = ds.tri_trips; out->wave_instance_steps = ds.inst_trips;
+    out->wave_node_steps = ds.node_trips; out->wave_tri_steps = ds.tri_trips; out->wave_instance_steps = ds.inst_trips; out->max_ray_steps = ds.max_ray_steps;
     out->traverse_launches = c->traverse_launches; out->traverse_ms = c->traverse_ms;
     out->blas_build_ms = c->blas_build_ms; out->tlas_build_ms = c->tlas_build_ms;
     out->blas_triangles = c->blas_triangles; out->tlas_instances = c->n_instances;

@@ -32,7 +32,8 @@ struct alignas(16) TriRec {
 struct alignas(16) InstRec {
     float world_to_object[12]; // S7
     const BvhNode* nodes;
-    const TriRec*  tris;
+    u32   tris_offset;         // byte offset of the BLAS's TriRec array from `nodes` (one allocation per BLAS)
+    float bound;               // nodes[0].bound, here so that entering an instance costs no dependent load
 };
 
 struct SceneView {
@@ -87,13 +88,19 @@ RT_DEV BoxRay make_box_ray(f3 o, f3 d, float bound) {
 }
 
 // returns entry distance; hit iff entry <= exit.  NaNs (0 * inf: origin exactly on a plane of a slab the ray is
-// parallel to) are dropped by min/max, which keeps the test conservative.
+// parallel to) are dropped by min/max, which keeps the test conservative.  A ray parallel to a slab and outside it
+// gives +-inf for both planes; the per-axis clamps (free: min3 / max3) keep those finite so that the padding below
+// cannot turn them into inf - inf = NaN, which would pass the box (seen: one such ray per ~8 M walked most of a
+// 52 k-instance TLAS and held a launch for 30 ms).
+#define RT_BOX_T_LIMIT 3.0e38f
 RT_DEV bool box_test(const BoxRay& r, const float* lo, const float* hi, float tmin, float tmax, float& entry) {
     float t0x = (lo[0] - r.ox) * r.idx, t1x = (hi[0] - r.ox) * r.idx;
     float t0y = (lo[1] - r.oy) * r.idy, t1y = (hi[1] - r.oy) * r.idy;
     float t0z = (lo[2] - r.oz) * r.idz, t1z = (hi[2] - r.oz) * r.idz;
-    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    float nx = fminf(fminf(t0x, t1x), RT_BOX_T_LIMIT), ny = fminf(fminf(t0y, t1y), RT_BOX_T_LIMIT), nz = fminf(fminf(t0z, t1z), RT_BOX_T_LIMIT);
+    float fx = fmaxf(fmaxf(t0x, t1x), -RT_BOX_T_LIMIT), fy = fmaxf(fmaxf(t0y, t1y), -RT_BOX_T_LIMIT), fz = fmaxf(fmaxf(t0z, t1z), -RT_BOX_T_LIMIT);
+    float tn = fmaxf(fmaxf(nx, ny), nz);
+    float tf = fminf(fminf(fx, fy), fz);
     tn = __builtin_fmaf(fabsf(tn), -2.0e-6f, tn - r.pad);
     tf = __builtin_fmaf(fabsf(tf), 2.0e-6f, tf + r.pad);
     entry = tn;
@@ -107,111 +114,124 @@ RT_DEV Quad ldq(const RT_GLOBAL void* base, int quad_index) { return ((const RT_
 
 #define RT_TRAVERSAL_DONE ((int) 0x80000001)
 
+// ---- closest-hit traversal ------------------------------------------------------------------------------------------
 // Closest hit with TMin < t < TMax, back faces culled, ties broken by the lowest (instance, primitive) (S5, S6).
-// `Stack` provides push(int) / pop() / empty(); COUNT enables the traversal counters.
-// MODE 0: one node or leaf step per loop trip ("if-if").  MODE 1: "while-while": every lane keeps descending inner
-// nodes until it holds a leaf, then the wave processes leaves together (fewer trips through the expensive leaf code
-// with few active lanes).
-template <class Stack, bool COUNT, int MODE>
-RT_DEV void trace_closest(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, Stack& st, HitOut& best,
-                          TraverseCounters& cnt) {
-    best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.inst = -1; best.tri = -1; best.prim_global = 0;
-    bool have_hit = false;
+// "while-while": every lane keeps descending inner nodes until it holds a leaf, then the wave processes leaves together.
+//
+// The per-ray state is a struct so that kernels can set a ray up (trace_begin) and run it (trace_run) separately.
+struct TraceState {
+    HitOut best;
+    bool have_hit, bottom, need_pop;
+    int cur_inst;  // instance being traversed (bottom level)
+    int cur;       // node link in hand, RT_TRAVERSAL_DONE when the ray is finished
+    const RT_GLOBAL BvhNode* nodes;
+    const RT_GLOBAL TriRec* tris;
+    BoxRay br;
+    RayPrep rp;
+};
+
+RT_DEV float tlas_bound_of(const SceneView& sc) { return ((const RT_GLOBAL BvhNode*) sc.tlas_nodes)[0].bound; }
+
+RT_DEV void trace_top_level(const SceneView& sc, f3 o, f3 d, TraceState& S) {
+    S.bottom = false;
+    S.nodes = (const RT_GLOBAL BvhNode*) sc.tlas_nodes;
+    S.br = make_box_ray(o, d, tlas_bound_of(sc));
+}
+
+// DXR semantics: inside an instance the ray is in object space and t is preserved
+RT_DEV void trace_bottom_level(const SceneView& sc, f3 o, f3 d, TraceState& S) {
+    const RT_GLOBAL InstRec* in = (const RT_GLOBAL InstRec*) sc.insts + S.cur_inst;
+    Quad m0 = ldq(in, 0), m1 = ldq(in, 1), m2 = ldq(in, 2), m3 = ldq(in, 3);
+    float w2o[12] = { m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w };
+    f3 oo = xform_point43(w2o, o);
+    f3 od = xform_dir43(w2o, d);
+    S.rp = prepare_ray(oo, od);
+    unsigned long long pn = ((unsigned long long) as_u32(m3.y) << 32) | as_u32(m3.x);
+    S.nodes = (const RT_GLOBAL BvhNode*) pn; S.tris = (const RT_GLOBAL TriRec*) (pn + as_u32(m3.z));
+    S.br = make_box_ray(oo, od, m3.w);
+    S.bottom = true;
+}
+
+RT_DEV void trace_begin(const SceneView& sc, f3 o, f3 d, float tmax, TraceState& S) {
+    S.best.t = tmax; S.best.u = 0.0f; S.best.v = 0.0f; S.best.inst = -1; S.best.tri = -1; S.best.prim_global = 0;
+    S.have_hit = false; S.need_pop = false; S.cur_inst = -1; S.tris = nullptr;
+    S.rp.o = o; S.rp.kx = 0; S.rp.ky = 1; S.rp.kz = 2; S.rp.sx = S.rp.sy = S.rp.sz = 0.0f;
+    trace_top_level(sc, o, d, S);
     // a NaN in the ray makes every triangle test fail (S4 compares with NaN are false): the answer is a miss, and
     // it must not cost a walk through the whole tree (NaN box tests pass conservatively).  Such rays do occur:
     // a shading normal perpendicular to the ray is scaled by sign(0) = 0 (raytracing.hlsl:64-65).
-    if (!(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z)) { best.t = inf_f32(); return; }
+    bool finite = o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z;
+    S.cur = finite ? 0 : RT_TRAVERSAL_DONE;
+}
 
-    const RT_GLOBAL BvhNode* const tlas_nodes = (const RT_GLOBAL BvhNode*) sc.tlas_nodes;
-    const RT_GLOBAL InstRec* const insts = (const RT_GLOBAL InstRec*) sc.insts;
-    const RT_GLOBAL BvhNode* nodes = tlas_nodes;
-    const RT_GLOBAL TriRec* tris = nullptr;
-    const float tlas_bound = tlas_nodes[0].bound;
-    BoxRay br = make_box_ray(o, d, tlas_bound);
-    RayPrep rp; rp.o = o; rp.kx = 0; rp.ky = 1; rp.kz = 2; rp.sx = rp.sy = rp.sz = 0.0f;
-    bool bottom = false;
-    int cur_inst = -1;
-    int cur = 0;
-    bool need_pop = false;
-
-    for (;;) {
+// Runs the ray to the end; S.best is then final (t = +inf for a miss).
+// `Stack` provides push(int) / pop() / empty(); COUNT enables the traversal counters.
+template <class Stack, bool COUNT>
+RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, Stack& st, TraceState& S, TraverseCounters& cnt) {
+    while (S.cur != RT_TRAVERSAL_DONE) {
         // ---- inner nodes ---------------------------------------------------------------------------------------
         for (;;) {
-            if (need_pop) {
-                need_pop = false;
-                if (st.empty()) cur = RT_TRAVERSAL_DONE;
+            if (S.need_pop) {
+                S.need_pop = false;
+                if (st.empty()) S.cur = RT_TRAVERSAL_DONE;
                 else {
-                    cur = st.pop();
-                    if (cur == RT_STACK_MARKER) { // back to the top level
-                        bottom = false;
-                        nodes = tlas_nodes;
-                        br = make_box_ray(o, d, tlas_bound);
-                        if (st.empty()) cur = RT_TRAVERSAL_DONE; else cur = st.pop();
+                    S.cur = st.pop();
+                    if (S.cur == RT_STACK_MARKER) { // back to the top level
+                        trace_top_level(sc, o, d, S);
+                        if (st.empty()) S.cur = RT_TRAVERSAL_DONE; else S.cur = st.pop();
                     }
                 }
             }
-            if (cur < 0) break;
-            const RT_GLOBAL BvhNode* n = nodes + cur;
+            if (S.cur < 0) break;
+            const RT_GLOBAL BvhNode* n = S.nodes + S.cur;
             Quad q0 = ldq(n, 0), q1 = ldq(n, 1), q2 = ldq(n, 2), q3 = ldq(n, 3);
             if (COUNT) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; }
             float lo0[3] = { q0.x, q0.y, q0.z }, hi0[3] = { q0.w, q1.x, q1.y };
             float lo1[3] = { q1.z, q1.w, q2.x }, hi1[3] = { q2.y, q2.z, q2.w };
             float e0, e1;
-            bool h0 = box_test(br, lo0, hi0, tmin, best.t, e0);
-            bool h1 = box_test(br, lo1, hi1, tmin, best.t, e1);
+            bool h0 = box_test(S.br, lo0, hi0, tmin, S.best.t, e0);
+            bool h1 = box_test(S.br, lo1, hi1, tmin, S.best.t, e1);
             int c0 = (int) as_u32(q3.x), c1 = (int) as_u32(q3.y);
             if (h0 && h1) {
                 bool first0 = e0 <= e1;
                 st.push(first0 ? c1 : c0);
-                cur = first0 ? c0 : c1;
-            } else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else need_pop = true;
-            if (MODE == 0 && !need_pop) break;
+                S.cur = first0 ? c0 : c1;
+            } else if (h0) S.cur = c0;
+            else if (h1) S.cur = c1;
+            else S.need_pop = true;
         }
-        if (MODE == 0 && cur >= 0) continue;
-        if (cur == RT_TRAVERSAL_DONE) break;
-        if (!bottom) {
-            // ---- TLAS leaf: enter the instance.  DXR semantics: the ray goes to object space, t is preserved ------
-            cur_inst = ~cur;
-            const RT_GLOBAL InstRec* in = insts + cur_inst;
-            Quad m0 = ldq(in, 0), m1 = ldq(in, 1), m2 = ldq(in, 2), m3 = ldq(in, 3);
+        if (S.cur == RT_TRAVERSAL_DONE) break;
+        if (!S.bottom) {
+            // ---- TLAS leaf: enter the instance ---------------------------------------------------------------------
+            S.cur_inst = ~S.cur;
             if (COUNT) { cnt.insts++; if (first_active_lane()) cnt.inst_trips++; }
-            float w2o[12] = { m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w };
-            f3 oo = xform_point43(w2o, o);
-            f3 od = xform_dir43(w2o, d);
-            rp = prepare_ray(oo, od);
-            unsigned long long pn = ((unsigned long long) as_u32(m3.y) << 32) | as_u32(m3.x);
-            unsigned long long pt = ((unsigned long long) as_u32(m3.w) << 32) | as_u32(m3.z);
-            nodes = (const RT_GLOBAL BvhNode*) pn; tris = (const RT_GLOBAL TriRec*) pt;
-            br = make_box_ray(oo, od, nodes[0].bound);
+            trace_bottom_level(sc, o, d, S);
             st.push(RT_STACK_MARKER);
-            bottom = true;
-            cur = 0;
+            S.cur = 0;
         } else {
             // ---- BLAS leaf: up to 8 triangles ------------------------------------------------------------------
-            int v = ~cur;
+            int v = ~S.cur;
             int first = v >> 3, count = (v & 7) + 1;
             for (int k = 0; k < count; k++) {
-                const RT_GLOBAL TriRec* tr = tris + first + k;
+                const RT_GLOBAL TriRec* tr = S.tris + first + k;
                 Quad a = ldq(tr, 0), b = ldq(tr, 1), c = ldq(tr, 2);
                 if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
                 float t, u, w;
-                if (!intersect_triangle(rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, w)) continue;
+                if (!intersect_triangle(S.rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, w)) continue;
                 if (!(t > tmin && t < tmax)) continue;
                 u32 prim_global = as_u32(c.y);
-                bool better = t < best.t;
-                if (!better && have_hit && t == best.t)
-                    better = cur_inst < best.inst || (cur_inst == best.inst && prim_global < best.prim_global);
+                bool better = t < S.best.t;
+                if (!better && S.have_hit && t == S.best.t)
+                    better = S.cur_inst < S.best.inst || (S.cur_inst == S.best.inst && prim_global < S.best.prim_global);
                 if (better) {
-                    best.t = t; best.u = u; best.v = w; best.inst = cur_inst; best.tri = first + k;
-                    best.prim_global = prim_global; have_hit = true;
+                    S.best.t = t; S.best.u = u; S.best.v = w; S.best.inst = S.cur_inst; S.best.tri = first + k;
+                    S.best.prim_global = prim_global; S.have_hit = true;
                 }
             }
-            need_pop = true;
+            S.need_pop = true;
         }
     }
-    if (!have_hit) best.t = inf_f32();
+    if (!S.have_hit) S.best.t = inf_f32();
 }
 
 } // namespace rtd

@@ -86,7 +86,7 @@ struct PathState {
 struct GatherQueue { u32* path; float *hx, *hy, *hz, *tf, *kx, *ky, *kz; int* ti; };
 
 struct DeviceStats { // lives in device memory
-    unsigned long long rays_camera, rays_probe, gather_pairs, nodes, tris, insts, node_trips, tri_trips, inst_trips;
+    unsigned long long rays_camera, rays_probe, gather_pairs, nodes, tris, insts, node_trips, tri_trips, inst_trips, max_ray_steps;
 };
 
 struct PassArgs {
@@ -124,7 +124,7 @@ struct PassArgs {
 
 int launch_probe_raygen(hipStream_t s, const PassArgs& a, u32 sample_index);
 // primary: bounce 0 of the camera pass (rays derived from pixels; in_queue unused)
-int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, int variant, bool primary, u32 sample_index);
+int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, bool primary, u32 sample_index);
 // fused: finished camera paths resolve their pixel in the shade kernel (no launch_camera_resolve afterwards)
 int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index, bool primary, bool fused);
 int launch_gather(hipStream_t s, const PassArgs& a);

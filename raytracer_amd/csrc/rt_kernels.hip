@@ -186,8 +186,24 @@ __global__ __launch_bounds__(BT) void k_probe_resolve(PassArgs a) {
 }
 
 // ---- TraceRay ---------------------------------------------------------------------------------------------------
+RT_DEV void traverse_counters_flush(const PassArgs& a, const TraverseCounters& cnt) {
+    u32 sn = wave_sum(cnt.nodes), stt = wave_sum(cnt.tris), si = wave_sum(cnt.insts);
+    u32 tn = wave_sum(cnt.node_trips), tt = wave_sum(cnt.tri_trips), ti = wave_sum(cnt.inst_trips);
+    u32 mx = cnt.nodes + cnt.tris + cnt.insts;
+    for (int off = 32; off >= 1; off >>= 1) { u32 o2 = __shfl_xor(mx, off); mx = o2 > mx ? o2 : mx; }
+    if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(&a.stats->nodes, (unsigned long long) sn);
+        atomicAdd(&a.stats->tris, (unsigned long long) stt);
+        atomicAdd(&a.stats->insts, (unsigned long long) si);
+        atomicAdd(&a.stats->node_trips, (unsigned long long) tn);
+        atomicAdd(&a.stats->tri_trips, (unsigned long long) tt);
+        atomicAdd(&a.stats->inst_trips, (unsigned long long) ti);
+        atomicMax(&a.stats->max_ray_steps, (unsigned long long) mx);
+    }
+}
+
 // PRIMARY: bounce 0 of the camera pass; lane t traces the primary ray of thread_pixel(t), the hit goes to slot t.
-template <bool COUNT, int MODE, int WAVES_PER_SIMD, bool PRIMARY>
+template <bool COUNT, int WAVES_PER_SIMD, bool PRIMARY>
 __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq, u32 sample_index) {
     __shared__ int smem[LDS_STACK_DEPTH * TRAVERSE_WAVE];
     const u32 qi = blockIdx.x * TRAVERSE_WAVE + threadIdx.x;
@@ -217,24 +233,13 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
     if (active) {
         LaneStack st; st.lds = (RT_LDS int*) &smem[threadIdx.x]; st.spill = (RT_GLOBAL int*) (a.stack_spill + qi);
         st.spill_stride = a.n_paths; st.sp = 0;
-        HitOut h;
-        trace_closest<LaneStack, COUNT, MODE>(a.scene, o, d, a.tmin, a.tmax, st, h, cnt);
-        a.hits.t[qi] = h.t; a.hits.u[qi] = h.u; a.hits.v[qi] = h.v; a.hits.inst[qi] = h.inst; a.hits.tri[qi] = h.tri;
+        TraceState S;
+        trace_begin(a.scene, o, d, a.tmax, S);
+        trace_run<LaneStack, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, S, cnt);
+        a.hits.t[qi] = S.best.t; a.hits.u[qi] = S.best.u; a.hits.v[qi] = S.best.v;
+        a.hits.inst[qi] = S.best.inst; a.hits.tri[qi] = S.best.tri;
     }
-    if (COUNT) {
-        u32 sn = wave_sum(cnt.nodes), stt = wave_sum(cnt.tris), si = wave_sum(cnt.insts);
-        if (threadIdx.x == 0) {
-            atomicAdd(&a.stats->nodes, (unsigned long long) sn);
-            atomicAdd(&a.stats->tris, (unsigned long long) stt);
-            atomicAdd(&a.stats->insts, (unsigned long long) si);
-        }
-        u32 tn = wave_sum(cnt.node_trips), tt = wave_sum(cnt.tri_trips), ti = wave_sum(cnt.inst_trips);
-        if (threadIdx.x == 0) {
-            atomicAdd(&a.stats->node_trips, (unsigned long long) tn);
-            atomicAdd(&a.stats->tri_trips, (unsigned long long) tt);
-            atomicAdd(&a.stats->inst_trips, (unsigned long long) ti);
-        }
-    }
+    if (COUNT) traverse_counters_flush(a, cnt);
 }
 
 // ---- hit / miss shaders + the tail of the trace_path_sample loop body (raytracing.hlsl:113-119) ------------------
@@ -403,19 +408,17 @@ int launch_probe_raygen(hipStream_t s, const PassArgs& a, u32 sample_index) {
     return RT_OK;
 }
 static size_t pass_paths(const PassArgs& a) { return (size_t) a.n_segments * SEG; }
-int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, int variant, bool primary, u32 sample_index) {
+int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, bool primary, u32 sample_index) {
     size_t n = pass_paths(a);
     if (!n) return RT_OK;
     dim3 grid = blocks(n, TRAVERSE_WAVE), block(TRAVERSE_WAVE);
-    // variant 0 = one node or leaf per loop trip ("if-if"); default = "while-while" (rt_dev_scene.h)
+    // 5 waves per SIMD = 96 VGPRs = what the LDS stacks allow as well (8 KB per wave)
     if (primary) {
-        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, 1, true>), grid, block, 0, s, a, in_queue, sample_index);
-        else if (variant == 0) hipLaunchKernelGGL((k_traverse<false, 0, 5, true>), grid, block, 0, s, a, in_queue, sample_index);
-        else hipLaunchKernelGGL((k_traverse<false, 1, 5, true>), grid, block, 0, s, a, in_queue, sample_index);
+        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true>), grid, block, 0, s, a, in_queue, sample_index);
+        else hipLaunchKernelGGL((k_traverse<false, 5, true>), grid, block, 0, s, a, in_queue, sample_index);
     } else {
-        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, 1, false>), grid, block, 0, s, a, in_queue, sample_index);
-        else if (variant == 0) hipLaunchKernelGGL((k_traverse<false, 0, 5, false>), grid, block, 0, s, a, in_queue, sample_index);
-        else hipLaunchKernelGGL((k_traverse<false, 1, 5, false>), grid, block, 0, s, a, in_queue, sample_index);
+        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, false>), grid, block, 0, s, a, in_queue, sample_index);
+        else hipLaunchKernelGGL((k_traverse<false, 5, false>), grid, block, 0, s, a, in_queue, sample_index);
     }
     RT_HIP(hipGetLastError());
     return RT_OK;

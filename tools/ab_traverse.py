@@ -1,21 +1,21 @@
 #!/usr/bin/env python3
-"""A/B of k_traverse variants in ONE process (interleaved rounds, cdna guide rule 24).
-usage: python tools/ab_traverse.py [variants...]   (RT_TRAVERSE_VARIANT values)"""
+"""A/B of traversal settings in ONE process (interleaved rounds, cdna guide rule 24).
+usage: python tools/ab_traverse.py [specs...]   spec = RT_BVH_BUILDER[:RT_SAH_TRI], e.g. 0  1  1:1.0  1:1.6"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from raytracer_amd import api, scenes, distributed, _abi
 
-# variant spec "T" or "T:B" = RT_TRAVERSE_VARIANT[:RT_BVH_BUILDER]
-variants = sys.argv[1:] or ["0", "1", "2"]
+variants = sys.argv[1:] or ["0", "1"]
 workloads = {"c2": lambda: scenes.bunny(1920, 1080, spp=1, bounces=1),
              "c3": lambda: scenes.cornell(1920, 1080, spp=4, bounces=4)}
 rounds, steps = 5, 6
 for wname, mk in workloads.items():
     ctxs = {}
     for v in variants:
-        os.environ["RT_TRAVERSE_VARIANT"] = v.split(":")[0]
-        os.environ["RT_BVH_BUILDER"] = v.split(":")[1] if ":" in v else "1"
+        f = v.split(":")
+        os.environ["RT_BVH_BUILDER"] = f[0]
+        os.environ["RT_SAH_TRI"] = f[1] if len(f) > 1 else "1.3"
         rt = api.Raytracer(0); sc = mk(); sc.setup(rt)
         rt.set_flags(sc.flags | _abi.RT_FLAG_TIME_KERNELS)
         ctxs[v] = (rt, sc, distributed.FrameChain(1), [0])
