@@ -179,6 +179,15 @@ def main():
         mean_launch_ms = stats["traverse_ms"] / launches
         rays_per_launch = rays / launches
         achieved = (b_trav * rays_per_launch) / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
+        # HBM bytes per k_traverse launch from the committed PMC passes of this same command (tools/pmc_passes.sh +
+        # tools/pmc_summary.py: FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as is); null for other workloads
+        traffic = None
+        if args.workload == "c2" and (args.width, args.height) == (1920, 1080):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                traffic = pmc["c2"]["kernels"]["k_traverse"]["traffic_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                traffic = None
         out = {
             "metric": "Mrays/s per GPU (primary+secondary) at 1080p" if (args.width, args.height) == (1920, 1080) else "Mrays/s (primary+secondary)",
             "value": total_rays / dt_max / 1e6,
@@ -191,7 +200,8 @@ def main():
                        "sample_points": points, "rays_per_step_per_gpu": rays / args.steps,
                        "parallelism": "sample-set split x%d + RCCL reduce" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_traverse", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": b_trav * rays_per_launch,
                          "bytes_per_ray_traverse": b_trav, "bytes_per_ray_pipeline": b_ray,
                          "mean_launch_ms": mean_launch_ms, "rays_per_launch": rays_per_launch,
                          "traverse_Mrays_s": rays / (stats["traverse_ms"] * 1e-3) / 1e6 if stats["traverse_ms"] > 0 else None,

@@ -27,8 +27,12 @@ def main():
     for f in files:
         for r in csv.DictReader(open(f)):
             k = short_name(r["Kernel_Name"])
-            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            launches[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+            names = [k]
+            if "<" in k and not k.startswith("k_traverse<true"):
+                names.append(k.split("<")[0])  # all instantiations of a kernel together (not the counting variant)
+            for k in names:
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                launches[k][r["Counter_Name"]].add((f, r["Dispatch_Id"]))
     kernels = {}
     for k, counters in acc.items():
         if not k.startswith("k_"):
