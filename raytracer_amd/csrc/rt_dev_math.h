@@ -5,8 +5,8 @@
 // are reproducible bit for bit; see DESIGN.md "Arithmetic contract" S1..S9.  Citations are file:line in the
 // reference tree (gluyas/raytracer).
 //
-// The functions are RT_DEV so that the same header also compiles as plain C++ for the CPU emulation tests
-// (tests/emu); the product only ever runs them on the GPU.
+// The functions are RT_DEV so that the header also parses in hipcc's host pass; the product only ever runs them
+// on the GPU (the CPU oracle under oracle/ is a separate, independent restatement).
 #pragma once
 #include <stdint.h>
 #include <math.h>
