@@ -208,6 +208,12 @@ def main():
                          "model_counts": model, "gpu_bvh_counts": gpu_counts},
             "cpu_baseline": cpu_line,
         }
+        if stats["gather_launches"] and stats["gather_ms"] > 0:
+            # second hot loop: (hit, sample point) pairs of translucent_chit; 24 B per pair from LDS
+            pairs_s = stats["gather_pairs"] / (stats["gather_ms"] * 1e-3)
+            out["gather"] = {"kernel": "k_gather", "pairs_per_s": pairs_s, "lds_GB_per_s": 24.0 * pairs_s / 1e9,
+                             "mean_launch_ms": stats["gather_ms"] / stats["gather_launches"],
+                             "share_of_step": stats["gather_ms"] / (dt * 1e3)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

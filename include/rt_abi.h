@@ -130,6 +130,8 @@ typedef struct RtStats {
     uint64_t wave_tri_steps;       /* 64-lane wave; lane steps / (64 * wave steps) = SIMD efficiency of the traversal    */
     uint64_t wave_instance_steps;
     uint64_t max_ray_steps;        /* RT_FLAG_COUNT_TRAVERSAL: most node + triangle + instance steps taken by one ray */
+    uint64_t gather_launches;      /* launches of the BSSRDF gather kernel (translucent_chit's loop, raytracing.hlsl:323-331) */
+    double   gather_ms;            /* their summed duration with RT_FLAG_TIME_KERNELS (HIP events on the context's stream) */
 } RtStats;
 
 /* rt_set_flags bits */

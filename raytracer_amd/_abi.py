@@ -63,7 +63,7 @@ class RtStats(C.Structure):
                 ("traverse_launches", C.c_uint64), ("traverse_ms", C.c_double), ("blas_build_ms", C.c_double),
                 ("tlas_build_ms", C.c_double), ("blas_triangles", C.c_uint64), ("tlas_instances", C.c_uint64),
                 ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64), ("wave_instance_steps", C.c_uint64),
-                ("max_ray_steps", C.c_uint64)]
+                ("max_ray_steps", C.c_uint64), ("gather_launches", C.c_uint64), ("gather_ms", C.c_double)]
 
 
 def load_library(path):

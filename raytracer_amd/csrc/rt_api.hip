@@ -81,7 +81,8 @@ struct rt_ctx {
     // BSSRDF tables
     float* d_table[2] = { nullptr, nullptr }; int table_texels[2] = { 0, 0 }; int profile = 0;
     // stats
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed; double traverse_ms = 0; uint64_t traverse_launches = 0, primary_rays = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, timed_gather; double traverse_ms = 0, gather_ms = 0;
+    uint64_t traverse_launches = 0, gather_launches = 0, primary_rays = 0;
     double blas_build_ms = 0, tlas_build_ms = 0; uint64_t blas_triangles = 0;
     rt_ctx() { memset(&g, 0, sizeof g); memset(q, 0, sizeof q); memset(&hits, 0, sizeof hits); memset(&ps, 0, sizeof ps); memset(&gq, 0, sizeof gq); }
 };
@@ -110,8 +111,8 @@ int ensure_path_buffers(rt_ctx* c) {
     u32 need = segs * 1024; // queue slots; path-state arrays are indexed by pixel / point id < need
     if (need <= c->n_paths) return RT_OK;
     dev_free(c->d_arena); dev_free(c->d_seg_count);
-    RT_HIP(hipMalloc(&c->d_seg_count, 3 * sizeof(u32) * (size_t) segs));
-    RT_HIP(hipMemset(c->d_seg_count, 0, 3 * sizeof(u32) * (size_t) segs));
+    RT_HIP(hipMalloc(&c->d_seg_count, sizeof(u32) * (4 * (size_t) segs + 1))); // 2 queues, gather, gather offsets
+    RT_HIP(hipMemset(c->d_seg_count, 0, sizeof(u32) * (4 * (size_t) segs + 1)));
     c->n_segments_cap = segs;
     const int n_arrays = 14 /* 2 queues x (6 + path) */ + 5 /* hits */ + 15 /* path state */ + 9 /* gather */ + 32 /* stack spill */;
     size_t stride = ((size_t) need + 63) & ~(size_t) 63;
@@ -162,6 +163,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.gather_enabled = (!probe && c->n_points > 0 && a.fudge != 0.0f) ? 1u : 0u;
     a.seg_count[0] = c->d_seg_count; a.seg_count[1] = c->d_seg_count + c->n_segments_cap;
     a.gseg_count = c->d_seg_count + 2 * (size_t) c->n_segments_cap;
+    a.goff = c->d_seg_count + 3 * (size_t) c->n_segments_cap;
     a.stack_spill = c->d_stack_spill;
     a.stats = c->d_stats;
     a.capture = nullptr;
@@ -196,7 +198,27 @@ int timed_traverse(rt_ctx* c, const PassArgs& a, u32 inq, bool primary, u32 samp
     return rc;
 }
 
+int timed_gather(rt_ctx* c, const PassArgs& a) {
+    bool timing = (c->flags & RT_FLAG_TIME_KERNELS) != 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) {
+        RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
+        RT_HIP(hipEventRecord(e0, c->stream));
+    }
+    int rc = launch_gather(c->stream, a);
+    if (timing) { RT_HIP(hipEventRecord(e1, c->stream)); c->timed_gather.emplace_back(e0, e1); }
+    c->gather_launches++;
+    return rc;
+}
+
 int drain_timers(rt_ctx* c) {
+    for (auto& pr : c->timed_gather) {
+        RT_HIP(hipEventSynchronize(pr.second));
+        float ms = 0; RT_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        c->gather_ms += ms;
+        (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second);
+    }
+    c->timed_gather.clear();
     for (auto& pr : c->timed) {
         RT_HIP(hipEventSynchronize(pr.second));
         float ms = 0; RT_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
@@ -233,7 +255,7 @@ int run_pass(rt_ctx* c, bool probe) {
             bool primary = !probe && b == 0;
             rc = timed_traverse(c, a, b & 1u, primary, s); if (rc) return rc;
             rc = launch_shade(c->stream, a, b & 1u, b, s, primary, fused); if (rc) return rc;
-            if (gather && (int) b <= c->g.translucent_emission_bounces) { rc = launch_gather(c->stream, a); if (rc) return rc; }
+            if (gather && (int) b <= c->g.translucent_emission_bounces) { rc = timed_gather(c, a); if (rc) return rc; }
         }
     }
     if (probe) return launch_probe_resolve(c->stream, a);
@@ -686,6 +708,7 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
     out->nodes_visited = ds.nodes; out->tris_tested = ds.tris; out->instances_entered = ds.insts;
     out->wave_node_steps = ds.node_trips; out->wave_tri_steps = ds.tri_trips; out->wave_instance_steps = ds.inst_trips; out->max_ray_steps = ds.max_ray_steps;
     out->traverse_launches = c->traverse_launches; out->traverse_ms = c->traverse_ms;
+    out->gather_launches = c->gather_launches; out->gather_ms = c->gather_ms;
     out->blas_build_ms = c->blas_build_ms; out->tlas_build_ms = c->tlas_build_ms;
     out->blas_triangles = c->blas_triangles; out->tlas_instances = c->n_instances;
     return RT_OK;
@@ -695,7 +718,7 @@ int rt_reset_stats(rt_ctx* c) {
     RT_HIP(hipStreamSynchronize(c->stream));
     int rc = drain_timers(c); if (rc) return rc;
     RT_HIP(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
-    c->traverse_ms = 0; c->traverse_launches = 0; c->primary_rays = 0;
+    c->traverse_ms = 0; c->traverse_launches = 0; c->primary_rays = 0; c->gather_ms = 0; c->gather_launches = 0;
     return RT_OK;
 }
 

@@ -6,7 +6,7 @@
 // reference tree (gluyas/raytracer).
 //
 // The functions are RT_DEV so that the header also parses in hipcc's host pass; the product only ever runs them
-// on the GPU (the CPU oracle under oracle/ is a separate, independent restatement).
+// on the GPU.
 #pragma once
 #include <stdint.h>
 #include <math.h>

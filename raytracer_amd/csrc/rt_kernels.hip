@@ -350,45 +350,147 @@ __global__ __launch_bounds__(SEG) void k_shade(PassArgs a, u32 inq, u32 bounce, 
 }
 
 // ---- translucent_chit: sum of bssrdf(|p_i - hit|) * payload_i over all sample points (raytracing.hlsl:321-333) -------
-__global__ __launch_bounds__(BT) void k_gather(PassArgs a) {
-    const u32 seg = blockIdx.x / (SEG / BT);
-    const u32 idx = (blockIdx.x % (SEG / BT)) * BT + threadIdx.x;
-    if (idx >= a.gseg_count[seg]) return;
-    const u32 i = seg * SEG + idx;
+// One hit per lane, every lane walks all points of its instance in index order (the order of the float sum is part of
+// the result).  The points are staged through LDS in tiles of GATHER_TILE (every lane reads the same point: an LDS
+// broadcast) and the tabulated profile sits in LDS as one float4 per texel, so the two texel fetches of the linear
+// filter are LDS gathers; reading both from global memory had the texture-address unit as the bottleneck
+// (12 divergent loads per pair).  Hits of different translucent instances in one workgroup take turns.
+static constexpr int GATHER_BLOCK = 256;
+static constexpr int GATHER_TILE = 512;        // points per tile: 16 KB
+static constexpr int GATHER_TABLE_MAX = 2048;  // texels kept in LDS: 32 KB (raytracing.cpp:113 pads the profile to 2048)
+
+struct alignas(16) GatherPoint { float px, py, pz, pad0, wx, wy, wz, pad1; };
+
+// S8 with the table in LDS as (r, g, b, 0) per texel; same arithmetic as sample_bssrdf_table, written without
+// branches (clamped addresses, selects) so that the unrolled gather loop can overlap the chains of several points
+RT_DEV f3 sample_bssrdf_table_lds(const float4* tab, int n, float u) {
+    float x = u * (float) n - 0.5f;
+    float fl = floorf(x);
+    float f = x - fl;
+    const bool in_range = fl >= -1.0f && fl < (float) n;
+    int i0 = in_range ? (int) fl : -2, i1 = i0 + 1;
+    const bool ok0 = i0 >= 0 && i0 < n, ok1 = i1 >= 0 && i1 < n;
+    float4 t0 = tab[ok0 ? i0 : 0], t1 = tab[ok1 ? i1 : 0];
+    f3 ta = ok0 ? mk3(t0.x, t0.y, t0.z) : mk3(0.0f, 0.0f, 0.0f);
+    f3 tb = ok1 ? mk3(t1.x, t1.y, t1.z) : mk3(0.0f, 0.0f, 0.0f);
+    f3 r = ta + f * (tb - ta);
+    return in_range ? r : mk3(0.0f, 0.0f, 0.0f);
+}
+
+// Gather items sit at the front of their 1024-slot segments; after the first bounce most segments hold only a few
+// (secondary rays that happen to reach a translucent mesh), so the gather kernel numbers the items across segments:
+// goff[s] = items in segments before s, goff[n_segments] = all of them.  One workgroup, wave scans with a carry.
+__global__ __launch_bounds__(SEG) void k_gather_offsets(PassArgs a) {
+    __shared__ u32 s_wave[SEG / 64];
+    __shared__ u32 s_carry;
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u32 b0 = 0; b0 < a.n_segments; b0 += SEG) {
+        const u32 i = b0 + threadIdx.x;
+        const u32 v = i < a.n_segments ? a.gseg_count[i] : 0u;
+        u32 inc = v;
+        for (int off = 1; off < 64; off <<= 1) { u32 t = __shfl_up(inc, off); if ((int) lane >= off) inc += t; }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        u32 base = s_carry, total = 0;
+        for (u32 w = 0; w < SEG / 64; w++) { u32 c = s_wave[w]; if (w < wave) base += c; total += c; }
+        if (i < a.n_segments) a.goff[i] = base + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.goff[a.n_segments] = s_carry;
+}
+
+// MODE: 0 = dipole, 1 = tabulated profile in LDS, 2 = tabulated profile too long for LDS (read from global memory);
+// a template parameter so that the unrolled loop body is straight-line code the scheduler can interleave
+template <int MODE>
+__global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
+    __shared__ GatherPoint s_pts[GATHER_TILE];
+    __shared__ float4 s_tab[GATHER_TABLE_MAX];
+    __shared__ int s_next;
+    const u32 n_items = a.goff[a.n_segments];
+    if (blockIdx.x * GATHER_BLOCK >= n_items) return; // uniform
+    const u32 j = blockIdx.x * GATHER_BLOCK + threadIdx.x;
+    const bool active = j < n_items;
+    u32 i;
+    {   // item j of the numbering -> its segment (last s with goff[s] <= j) -> its queue slot
+        const u32 jj = active ? j : n_items - 1u;
+        u32 lo = 0, hi = a.n_segments; // goff[lo] <= jj < goff[hi]
+        while (hi - lo > 1u) { u32 mid = (lo + hi) >> 1; if (a.goff[mid] <= jj) lo = mid; else hi = mid; }
+        i = lo * SEG + (jj - a.goff[lo]);
+    }
     const GatherQueue& g = a.gq;
-    u32 path = g.path[i];
-    f3 hit = mk3(g.hx[i], g.hy[i], g.hz[i]);
-    const TranslucentSlice& sl = a.shade.slices[g.ti[i]];
-    const RtSamplePoint* pts = a.sp_read + sl.offset;
-    f3 E = mk3(0.0f, 0.0f, 0.0f);
+    const f3 hit = mk3(g.hx[i], g.hy[i], g.hz[i]);
+    const int my_ti = active ? g.ti[i] : -1;
     const float scale = a.g.translucent_bssrdf_scale;
-    if (scale != 0.0f) {
-        const float z = scale * scale;
-        for (u32 k = 0; k < sl.count; k++) {
-            const RtSamplePoint sp = pts[k];
-            f3 dp = mk3(sp.position[0], sp.position[1], sp.position[2]) - hit;
-            float radius = sqrtf(dot3(dp, dp));
-            f3 b = (a.fudge * sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, radius / scale)) / z; // :272-276
-            E = E + b * mk3(sp.payload[0], sp.payload[1], sp.payload[2]);
-        }
-    } else {
-        const float eta = a.g.translucent_refractive_index;
-        DipoleConst cr = dipole_constants(a.g.translucent_scattering[0], a.g.translucent_absorption[0], eta);
-        DipoleConst cg = dipole_constants(a.g.translucent_scattering[1], a.g.translucent_absorption[1], eta);
-        DipoleConst cb = dipole_constants(a.g.translucent_scattering[2], a.g.translucent_absorption[2], eta);
-        for (u32 k = 0; k < sl.count; k++) {
-            const RtSamplePoint sp = pts[k];
-            f3 dp = mk3(sp.position[0], sp.position[1], sp.position[2]) - hit;
-            float radius = sqrtf(dot3(dp, dp));
-            f3 b = mk3(dipole_eval(cr, radius), dipole_eval(cg, radius), dipole_eval(cb, radius));        // :278-301
-            E = E + b * mk3(sp.payload[0], sp.payload[1], sp.payload[2]);
+    if (MODE == 1)
+        for (int t = threadIdx.x; t < a.bssrdf_texels; t += GATHER_BLOCK)
+            s_tab[t] = make_float4(a.bssrdf_table[3 * t], a.bssrdf_table[3 * t + 1], a.bssrdf_table[3 * t + 2], 0.0f);
+    const float z = scale * scale;
+    const float eta = a.g.translucent_refractive_index;
+    DipoleConst cr = dipole_constants(a.g.translucent_scattering[0], a.g.translucent_absorption[0], eta);
+    DipoleConst cg = dipole_constants(a.g.translucent_scattering[1], a.g.translucent_absorption[1], eta);
+    DipoleConst cb = dipole_constants(a.g.translucent_scattering[2], a.g.translucent_absorption[2], eta);
+    f3 E = mk3(0.0f, 0.0f, 0.0f);
+    u32 pairs = 0;
+    // translucent instances present in this workgroup, in increasing index order
+    int cur = -1;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = 0x7fffffff;
+        __syncthreads();
+        if (my_ti > cur) atomicMin(&s_next, my_ti);
+        __syncthreads();
+        cur = s_next;
+        if (cur == 0x7fffffff) break; // uniform
+        const TranslucentSlice sl = a.shade.slices[cur];
+        const RtSamplePoint* pts = a.sp_read + sl.offset;
+        const bool mine = my_ti == cur;
+        for (u32 k0 = 0; k0 < sl.count; k0 += GATHER_TILE) {
+            const u32 nk = sl.count - k0 < (u32) GATHER_TILE ? sl.count - k0 : (u32) GATHER_TILE;
+            __syncthreads(); // the previous tile is no longer read
+            for (u32 t = threadIdx.x; t < nk; t += GATHER_BLOCK) {
+                const RtSamplePoint sp = pts[k0 + t];
+                GatherPoint gp;
+                gp.px = sp.position[0]; gp.py = sp.position[1]; gp.pz = sp.position[2]; gp.pad0 = 0.0f;
+                gp.wx = sp.payload[0]; gp.wy = sp.payload[1]; gp.wz = sp.payload[2]; gp.pad1 = 0.0f;
+                s_pts[t] = gp;
+            }
+            __syncthreads();
+            if (!mine) continue;
+            // four points per trip: their sqrt / divide chains are independent and overlap; the sum stays in index order
+            auto term = [&](u32 k) -> f3 {
+                const GatherPoint gp = s_pts[k];
+                f3 dp = mk3(gp.px, gp.py, gp.pz) - hit;
+                float radius = sqrtf(dot3(dp, dp));
+                f3 bs;
+                if (MODE != 0) {
+                    f3 tv = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, radius / scale)
+                                      : sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, radius / scale);
+                    bs = (a.fudge * tv) / z;                                                                 // :272-276
+                } else bs = mk3(dipole_eval(cr, radius), dipole_eval(cg, radius), dipole_eval(cb, radius));  // :278-301
+                return bs * mk3(gp.wx, gp.wy, gp.wz);
+            };
+            u32 k = 0;
+            for (; k + 4 <= nk; k += 4) {
+                f3 c0 = term(k), c1 = term(k + 1), c2 = term(k + 2), c3 = term(k + 3);
+                E = E + c0; E = E + c1; E = E + c2; E = E + c3;
+            }
+            for (; k < nk; k++) E = E + term(k);
+            pairs += nk;
         }
     }
-    E = E / (float) (a.g.translucent_accumulator_count + 1u);                                           // :332
-    f3 emission = E * g.tf[i] / (RT_TAU_F / 2.0f);                                                     // :347
-    f3 k3 = mk3(g.kx[i], g.ky[i], g.kz[i]);
-    a.ps.rad_x[path] += emission.x * k3.x; a.ps.rad_y[path] += emission.y * k3.y; a.ps.rad_z[path] += emission.z * k3.z;
-    atomicAdd(&a.stats->gather_pairs, (unsigned long long) sl.count);
+    if (active) {
+        E = E / (float) (a.g.translucent_accumulator_count + 1u);                                       // :332
+        f3 emission = E * g.tf[i] / (RT_TAU_F / 2.0f);                                                 // :347
+        f3 k3 = mk3(g.kx[i], g.ky[i], g.kz[i]);
+        const u32 path = g.path[i];
+        a.ps.rad_x[path] += emission.x * k3.x; a.ps.rad_y[path] += emission.y * k3.y; a.ps.rad_z[path] += emission.z * k3.z;
+    }
+    pairs = wave_sum(active ? pairs : 0u);
+    if ((threadIdx.x & 63u) == 0 && pairs) atomicAdd(&a.stats->gather_pairs, (unsigned long long) pairs);
 }
 
 __global__ __launch_bounds__(BT) void k_fill_capture(RtHit* capture, size_t n) {
@@ -437,7 +539,11 @@ int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32
 int launch_gather(hipStream_t s, const PassArgs& a) {
     size_t n = pass_paths(a);
     if (!n) return RT_OK;
-    hipLaunchKernelGGL(k_gather, blocks(n, BT), dim3(BT), 0, s, a);
+    hipLaunchKernelGGL(k_gather_offsets, dim3(1), dim3(SEG), 0, s, a);
+    dim3 grid = blocks(n, GATHER_BLOCK), block(GATHER_BLOCK);
+    if (a.g.translucent_bssrdf_scale == 0.0f) hipLaunchKernelGGL(k_gather<0>, grid, block, 0, s, a); // raytracing.hlsl:316-320
+    else if (a.bssrdf_texels <= GATHER_TABLE_MAX) hipLaunchKernelGGL(k_gather<1>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(k_gather<2>, grid, block, 0, s, a);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
