@@ -1,0 +1,183 @@
+"""GPU parity on the corner cases of the path: tiny and ragged resolutions, degenerate and duplicated triangles
+(the S5 tie-break), shared edges (watertightness, S4), the 16-bit index limit, one-triangle meshes, zero bounces,
+mirrored / non-uniform instance transforms, and the status codes of the C-ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracer_amd import scenes, _abi, host
+import parity_util as pu
+
+pytestmark = pytest.mark.gpu
+
+LAMBERT, LIGHT = _abi.RT_SHADER_LAMBERT, _abi.RT_SHADER_LIGHT
+
+
+def _check(scene, oracle_mod, frames=1):
+    from raytracer_amd import api
+    gpu = api.Raytracer(0)
+    cpu = oracle_mod.Oracle(brute_force=True, threads=8)
+    try:
+        pu.run_pair(scene, gpu, cpu, frames=frames)
+        rays = 0
+        for b in range(scene.globals.bounces_per_sample + 1):
+            rays += pu.compare_hits(gpu.read_hit_records(b), cpu.read_hit_records(b), b)
+        pu.compare_images(gpu.read_accumulator(), cpu.read_accumulator())
+        return rays, gpu.read_hit_records(0)
+    finally:
+        gpu.close(); cpu.close()
+
+
+def _mesh(tris):
+    """tris: (n, 3, 3) positions -> flat-shaded vertices (normal = normalised cross product, +z for degenerate)"""
+    tris = np.asarray(tris, dtype=np.float32)
+    v = np.zeros(len(tris) * 3, dtype=_abi.VERTEX_DTYPE)
+    for k, t in enumerate(tris):
+        n = np.cross(t[1] - t[0], t[2] - t[0]).astype(np.float64)
+        ln = np.linalg.norm(n)
+        n = n / ln if ln > 0 else np.array([0.0, 0.0, 1.0])
+        for j in range(3):
+            v["position"][3 * k + j] = t[j]
+            v["normal"][3 * k + j] = n
+    return v, np.arange(len(tris) * 3, dtype=np.uint16)
+
+
+def _light_and_floor(s):
+    lv, li = host.quad((-0.5, -0.5, 0.9), (-0.5, 0.5, 0.9), (0.5, 0.5, 0.9), (0.5, -0.5, 0.9))
+    fv, fi = host.quad((-1.5, -1.5, -0.3), (1.5, -1.5, -0.3), (1.5, 1.5, -0.3), (-1.5, 1.5, -0.3))
+    s.blas.append([scenes._geo(fv, fi, LAMBERT, (0.8, 0.8, 0.8)), scenes._geo(lv, li, LIGHT, (0.0, 0.0, 0.0))])
+    s.instances.append((np.eye(4, dtype=np.float32), len(s.blas) - 1))
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (33, 1), (1, 35), (31, 33), (64, 2)])
+def test_tiny_and_ragged_resolutions(oracle_mod, w, h):
+    rays, _ = _check(scenes.debug_cube(w, h, spp=2, bounces=2), oracle_mod, frames=2)
+    assert rays >= w * h
+
+
+def test_zero_bounces_and_many_samples(oracle_mod):
+    _check(scenes.cornell(40, 30, spp=7, bounces=0), oracle_mod, frames=2)
+
+
+def test_duplicate_and_degenerate_triangles_tie_break(oracle_mod):
+    """the same wall three times in one BLAS (geometry 0 prims 0-1, geometry 1 prims 0-1) and again as a second
+    instance, plus zero-area triangles: S5 says the lowest (instance, primitive) wins, degenerates never hit"""
+    s = scenes.SceneDesc("dupes", 48, 40)
+    a, b, c, d = (-0.6, 0.3, -0.3), (0.6, 0.3, -0.3), (0.6, 0.3, 0.6), (-0.6, 0.3, 0.6)  # faces the camera at -y
+    wall = [[a, b, c], [a, c, d]]
+    degenerate = [[a, a, b], [a, b, b], [c, c, c], [a, (0.0, 0.3, -0.3), b]]             # repeated / collinear vertices
+    v0, i0 = _mesh(wall + degenerate)
+    v1, i1 = _mesh(wall)
+    s.blas.append([scenes._geo(v0, i0, LAMBERT, (0.9, 0.2, 0.2)), scenes._geo(v1, i1, LAMBERT, (0.2, 0.9, 0.2))])
+    s.instances.append((np.eye(4, dtype=np.float32), 0))
+    s.instances.append((np.eye(4, dtype=np.float32), 0))
+    _light_and_floor(s)
+    s.globals.samples_per_pixel = 1
+    s.globals.bounces_per_sample = 2
+    _, hits = _check(s, oracle_mod)
+    on_wall = hits["instance"] == 0
+    assert on_wall.sum() > 100 and not (hits["instance"] == 1).any()      # the second copy never wins a tie
+    assert (hits["geometry"][on_wall] == 0).all() and (hits["primitive"][on_wall] <= 1).all()
+
+
+def test_shared_edges_are_watertight(oracle_mod):
+    """a fan of 64 thin triangles around a point straight ahead of the camera: every primary ray through the disc
+    hits exactly one of them (no leaks along the shared edges, no double hits), ids equal to the oracle's"""
+    s = scenes.SceneDesc("fan", 96, 96)
+    n = 64
+    ring = [(0.5 * np.cos(2 * np.pi * k / n), 0.4, 0.2 + 0.5 * np.sin(2 * np.pi * k / n)) for k in range(n)]
+    centre = (0.0, 0.4, 0.2)
+    tris = [[centre, ring[k], ring[(k + 1) % n]] for k in range(n)]
+    v, i = _mesh(tris)
+    # make it face the camera whichever way the winding came out: add the mirrored copy as a second geometry
+    v2, i2 = _mesh([[t[0], t[2], t[1]] for t in tris])
+    s.blas.append([scenes._geo(v, i, LAMBERT, (0.9, 0.9, 0.9)), scenes._geo(v2, i2, LAMBERT, (0.9, 0.9, 0.9))])
+    s.instances.append((np.eye(4, dtype=np.float32), 0))
+    _light_and_floor(s)
+    s.globals.samples_per_pixel = 1
+    s.globals.bounces_per_sample = 1
+    _, hits = _check(s, oracle_mod)
+    assert (hits["instance"] == 0).sum() > 500
+
+
+def test_sixteen_bit_index_limit(oracle_mod):
+    """a BLAS of exactly 65,535 vertices: the indices of all geometries are rebased into one concatenated vertex
+    buffer (raytracing.cpp:360-366) that 16-bit indices must address (:367); one vertex more is refused"""
+    rs = np.random.RandomState(5)
+    n = 21844
+    c = rs.uniform(-0.5, 0.5, (n, 1, 3)) * np.array([1.0, 1.0, 0.6]) + np.array([0.0, 0.0, 0.25])
+    tris = c + rs.uniform(-0.03, 0.03, (n, 3, 3))
+    v, i = _mesh(tris)
+    assert len(v) == 65532
+    s = scenes.SceneDesc("max_indices", 64, 48)
+    v2, i2 = _mesh([[(-0.9, -0.9, -0.25), (0.9, -0.9, -0.25), (0.0, 0.9, -0.25)]])
+    s.blas.append([scenes._geo(v, i, LAMBERT, (0.7, 0.7, 0.9)), scenes._geo(v2, i2, LAMBERT, (0.9, 0.7, 0.7))])
+    s.instances.append((np.eye(4, dtype=np.float32), 0))
+    _light_and_floor(s)
+    s.globals.samples_per_pixel = 1
+    s.globals.bounces_per_sample = 2
+    _, hits = _check(s, oracle_mod)
+    assert (hits["geometry"] == 1).any()  # the rebased triangle of the second geometry is seen
+    from raytracer_amd import api
+    rt = api.Raytracer(0)
+    try:
+        v3, i3 = _mesh([[(0, 0, 0), (1, 0, 0), (0, 1, 0)], [(0, 0, 1), (1, 0, 1), (0, 1, 1)]])
+        with pytest.raises(RuntimeError, match="16-bit"):
+            rt.build_blas([scenes._geo(v, i, LAMBERT, (1, 1, 1)), scenes._geo(v3, i3, LAMBERT, (1, 1, 1))])
+    finally:
+        rt.close()
+
+
+def test_single_triangle_meshes_and_mirrored_transforms(oracle_mod):
+    """BLAS of one triangle (root with an absent child), instanced with non-uniform scale, shear-free rotation and a
+    mirror (negative determinant flips the facing in world space; culling is decided in object space)"""
+    s = scenes.SceneDesc("singles", 80, 60)
+    v, i = _mesh([[(-0.5, 0.0, -0.2), (0.5, 0.0, -0.2), (0.0, 0.0, 0.6)]])
+    vb, ib = _mesh([[(-0.5, 0.0, -0.2), (0.0, 0.0, 0.6), (0.5, 0.0, -0.2)]])
+    s.blas.append([scenes._geo(v, i, LAMBERT, (0.9, 0.5, 0.1))])
+    s.blas.append([scenes._geo(vb, ib, LAMBERT, (0.1, 0.5, 0.9))])
+    def xf(sx, sy, sz, angle, t):
+        m = np.eye(4, dtype=np.float32)
+        ca, sa = np.float32(np.cos(angle)), np.float32(np.sin(angle))
+        m[0, 0], m[0, 1], m[1, 0], m[1, 1] = ca * sx, sa * sx, -sa * sy, ca * sy
+        m[2, 2] = sz
+        m[3, :3] = t
+        return m
+    s.instances += [(xf(1.0, 1.0, 1.0, 0.0, (0.0, 0.5, 0.0)), 0), (xf(0.5, 2.0, 0.7, 0.4, (-0.5, 0.2, 0.1)), 1),
+                    (xf(-1.0, 1.0, 1.0, 0.0, (0.5, 0.3, 0.0)), 0), (xf(0.6, 0.6, -1.2, 1.1, (0.2, 0.0, 0.3)), 1)]
+    _light_and_floor(s)
+    s.globals.samples_per_pixel = 2
+    s.globals.bounces_per_sample = 3
+    _check(s, oracle_mod, frames=2)
+
+
+def test_status_codes_instead_of_abort():
+    """prelude.h:185 aborts; the C-ABI returns a status and a message and stays usable"""
+    from raytracer_amd import api
+    rt = api.Raytracer(0)
+    try:
+        lib, h = rt.lib, rt.h
+        lib.rt_last_error.restype = C.c_char_p
+        assert lib.rt_dispatch_rays(h) != _abi.RT_OK                       # nothing built yet
+        assert len(lib.rt_last_error()) > 0
+        assert lib.rt_update_resolution(h, C.c_uint32(0), C.c_uint32(16)) != _abi.RT_OK
+        inst = _abi.instance_array([(np.eye(4, dtype=np.float32), 7)])
+        assert lib.rt_build_tlas(h, inst, C.c_int(1)) != _abi.RT_OK        # BLAS handle 7 does not exist
+        out = C.c_int32(-1)
+        assert lib.rt_build_blas(h, None, C.c_int(0), C.byref(out)) != _abi.RT_OK
+        v, i = _mesh([[(0, 0, 0), (1, 0, 0), (0, 1, 0)]])
+        bad = i.copy(); bad[2] = 9                                         # index past the vertex array
+        arr, keep = _abi.geometry_array([scenes._geo(v, bad, LAMBERT, (1, 1, 1))])
+        assert lib.rt_build_blas(h, arr, C.c_int(1), C.byref(out)) != _abi.RT_OK
+        arr, keep = _abi.geometry_array([scenes._geo(v, i[:2], LAMBERT, (1, 1, 1))])   # not a multiple of 3
+        assert lib.rt_build_blas(h, arr, C.c_int(1), C.byref(out)) != _abi.RT_OK
+        # and the context still works afterwards
+        s = scenes.debug_cube(16, 16, 1, 1)
+        s.setup(rt)
+        rt.dispatch_rays()
+        assert np.isfinite(rt.read_accumulator()).all()
+        buf = np.empty(16 * 16, dtype=_abi.HIT_DTYPE)
+        assert lib.rt_read_hit_records(h, C.c_uint32(0), C.c_void_p(buf.ctypes.data)) != _abi.RT_OK  # capture flag not set
+    finally:
+        rt.close()
