@@ -45,7 +45,7 @@ def build_scene(name, args):
     if name == "c3t":
         return scenes.cornell(args.width, args.height, spp=args.spp or 1, bounces=4, translucent_boxes=True), "c3t: cornell as shipped (dipole BSSRDF)"
     if name == "c4":
-        return scenes.cornell_bunny(args.width, args.height, spp=args.spp or 16, bounces=4), "c4: cornell + translucent bunny skin_0 %dspp" % (args.spp or 16)
+        return scenes.cornell_bunny(args.width, args.height, spp=args.spp or 16, bounces=4, sample_radius=args.sample_radius), "c4: cornell + translucent bunny skin_0 %dspp" % (args.spp or 16)
     if name == "c5":
         return scenes.bunny_field(args.width, args.height, spp=1, bounces=4, count=args.instances), "c5: %d instanced bunnies" % args.instances
     raise SystemExit("unknown workload " + name)
@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--instances", type=int, default=52743)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sample-radius", type=float, default=0.025, help="blue-noise rejection radius of c4 (main.cpp:50)")
+    ap.add_argument("--hg", type=float, default=None, metavar="STERADIANS",
+                    help="hierarchical BSSRDF gather with this solid-angle limit (rt_set_gather_mode; not reference behaviour)")
     args = ap.parse_args()
 
     import torch
@@ -108,6 +111,9 @@ def main():
 
     from raytracer_amd import api, host, _abi
     scene, label = build_scene(args.workload, args)
+    if args.hg is not None:
+        scene.gather_mode = (True, args.hg)
+        label += " [hierarchical gather, limit %g sr]" % args.hg
     rt = api.Raytracer(local_rank)
     points = scene.setup(rt)
     acc_ptr, acc_bytes = rt.accumulator_device_ptr()

@@ -186,6 +186,15 @@ int  rt_set_flags(rt_ctx* ctx, uint32_t flags);
  * (the one the reference includes, raytracing.cpp:112), profile 1 = data/skin_1.h.  Blocks. */
 int  rt_load_bssrdf_table(rt_ctx* ctx, int profile, const float* r, const float* g, const float* b, uint32_t n);
 int  rt_set_bssrdf_profile(rt_ctx* ctx, int profile);
+/* Hierarchical evaluation of translucent_chit's sum over the sample points (raytracing.hlsl:323-331).  The reference
+ * has only the O(points) loop and lists the hierarchy as future work (todo.txt:1-2); this is SURVEY.md 8 row f4.
+ * hierarchical = 0 (default): the reference's loop, point by point in index order.
+ * hierarchical = 1: a tree over each instance's points (Morton order, midpoint splits, leaves of <= 8 points); a node
+ * whose points lie in a sphere not containing the hit and that subtends less than max_solid_angle steradians
+ * (count * mean_area < max_solid_angle * distance^2) contributes bssrdf(distance to its centroid) * sum of payloads
+ * (Jensen & Buhler 2002).  Results change (an approximation; 0 visits every point, in tree order); the exact
+ * definition is DESIGN.md section 8.  Takes effect from the next rt_dispatch_rays. */
+int  rt_set_gather_mode(rt_ctx* ctx, int hierarchical, float max_solid_angle);
 
 /* Raytracing::dispatch_rays (raytracing.cpp:652-747): [translucent_rgen] -> copy -> camera_rgen, then
  * accumulator_count += 1 and translucent_accumulator_count += collect (raytracing.cpp:744-745). */

@@ -162,7 +162,18 @@ struct Instance {
     V3    wlo, whi;    // world AABB (oracle BVH culling only)
 };
 
+// Hierarchical evaluation of the sample-point sum (the reference only plans it, todo.txt:1-2).
+// Not reference behaviour: an approximation behind orc_set_gather_mode, specified in DESIGN.md section 8 (HG-1..HG-6)
+// and restated here independently of the product.
+struct HgNode { float centre[3]; float radius2; u32 first, count, right, depth; };
+struct HgTree {
+    std::vector<HgNode> nodes;      // preorder: the left child of node i is i + 1
+    std::vector<u32> order;         // sorted position -> index in generation order
+    std::vector<V3> sums;           // per node, refreshed when the read buffer changes
+};
+
 struct TranslucentInstance { // raytracing.cpp:54-65
+    HgTree hg;
     u32 translucent_id, instance_id;
     float transform[16];
     float scale_factor;
@@ -202,8 +213,9 @@ struct Scene {
     int threads;
     Counters counters;
     u32 tile_rank, tile_world;
+    bool hg_enabled; float hg_max_solid_angle;
     Scene() : flags(RT_FLAG_COLLECT_SAMPLES | RT_FLAG_ENABLE_SSS), width(0), height(0), profile(0),
-              brute_force(true), threads(1), tile_rank(0), tile_world(1) {
+              brute_force(true), threads(1), tile_rank(0), tile_world(1), hg_enabled(false), hg_max_solid_angle(0.0f) {
         memset(&g, 0, sizeof g);
         memset(&counters, 0, sizeof counters);
         bssrdf_texels[0] = bssrdf_texels[1] = 0;
@@ -608,6 +620,110 @@ void light_chit(const Scene& s, const Geometry& geo, const Hit& h, V3 dir, RayPa
 void miss(RayPayload& p) {
     p.scatter = v3(0, 0, 0); p.reflectance = v3(0, 0, 0); p.emission = v3(0, 0, 0); p.t = F_INF;
 }
+// HG-1..HG-4: Morton order of the points, implicit midpoint tree in preorder, leaves of <= 8 points
+u32 hg_part1by2(u32 x) {
+    x &= 0x3ffu; x = (x | (x << 16)) & 0x030000ffu; x = (x | (x << 8)) & 0x0300f00fu;
+    x = (x | (x << 4)) & 0x030c30c3u; x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+u32 hg_build_node(HgTree& t, const std::vector<RtSamplePoint>& pts, u32 first, u32 count, u32 depth) {
+    u32 id = (u32) t.nodes.size();
+    t.nodes.push_back(HgNode());
+    double sum[3] = { 0, 0, 0 };
+    for (u32 j = 0; j < count; j++) for (int a = 0; a < 3; a++) sum[a] += (double) pts[t.order[first + j]].position[a];
+    HgNode n;
+    for (int a = 0; a < 3; a++) n.centre[a] = (float) (sum[a] / (double) count);
+    n.radius2 = 0.0f;
+    for (u32 j = 0; j < count; j++) {
+        V3 d = ld3(pts[t.order[first + j]].position) - ld3(n.centre);
+        float d2 = dot(d, d);
+        if (d2 > n.radius2) n.radius2 = d2;
+    }
+    n.first = first; n.count = count; n.right = 0; n.depth = depth;
+    if (count > 8) {
+        u32 half = (count + 1) / 2;
+        hg_build_node(t, pts, first, half, depth + 1);
+        n.right = hg_build_node(t, pts, first + half, count - half, depth + 1);
+    }
+    t.nodes[id] = n;
+    return id;
+}
+void hg_build(TranslucentInstance& ti) {
+    HgTree& t = ti.hg;
+    t.nodes.clear(); t.order.clear(); t.sums.clear();
+    const std::vector<RtSamplePoint>& pts = ti.sample_points;
+    u32 n = (u32) pts.size();
+    if (!n) return;
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; a++) { lo[a] = pts[0].position[a]; hi[a] = pts[0].position[a]; }
+    for (u32 k = 1; k < n; k++) for (int a = 0; a < 3; a++) {
+        lo[a] = fminf(lo[a], pts[k].position[a]); hi[a] = fmaxf(hi[a], pts[k].position[a]);
+    }
+    std::vector<std::pair<u32, u32> > keyed(n);
+    for (u32 k = 0; k < n; k++) {
+        u32 q[3];
+        for (int a = 0; a < 3; a++) {
+            float e = hi[a] - lo[a];
+            q[a] = e > 0.0f ? (u32) fminf(fmaxf((pts[k].position[a] - lo[a]) / e * 1024.0f, 0.0f), 1023.0f) : 0u;
+        }
+        keyed[k] = std::make_pair(hg_part1by2(q[0]) | (hg_part1by2(q[1]) << 1) | (hg_part1by2(q[2]) << 2), k);
+    }
+    std::sort(keyed.begin(), keyed.end());
+    t.order.resize(n);
+    for (u32 k = 0; k < n; k++) t.order[k] = keyed[k].second;
+    hg_build_node(t, pts, 0, n, 0);
+}
+// HG-5: node sums of the read buffer's payloads (leaf: sequential in sorted order from 0; inner: left + right)
+V3 hg_sum_node(HgTree& t, const std::vector<RtSamplePoint>& pts, u32 id) {
+    const HgNode& n = t.nodes[id];
+    V3 sum = v3(0, 0, 0);
+    if (n.right == 0) for (u32 j = 0; j < n.count; j++) sum = sum + ld3(pts[t.order[n.first + j]].payload);
+    else { V3 l = hg_sum_node(t, pts, id + 1); V3 r = hg_sum_node(t, pts, n.right); sum = l + r; }
+    t.sums[id] = sum;
+    return sum;
+}
+void hg_refresh(TranslucentInstance& ti) {
+    if (ti.hg.nodes.empty()) return;
+    ti.hg.sums.assign(ti.hg.nodes.size(), v3(0, 0, 0));
+    hg_sum_node(ti.hg, ti.sample_points, 0);
+}
+V3 eval_bssrdf(const Scene& s, float fudge, float radius) {
+    if (s.g.translucent_bssrdf_scale != 0.0f) {
+        float z = s.g.translucent_bssrdf_scale * s.g.translucent_bssrdf_scale;
+        return (fudge * sample_bssrdf_table(s, radius / s.g.translucent_bssrdf_scale)) / z;
+    }
+    return eval_bssrdf_dipole(s, radius);
+}
+// HG-6: preorder walk, left before right; a node stands for its points when the hit is outside its bounding sphere
+// and it subtends less than the solid-angle limit: count * mean_area < limit * distance^2
+V3 hg_gather(const Scene& s, const TranslucentInstance& ti, float mean_area, float fudge, V3 hit_point, u64* pairs) {
+    const HgTree& t = ti.hg;
+    V3 sum = v3(0, 0, 0);
+    if (t.nodes.empty()) return sum;
+    u32 stack[64]; int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        u32 id = stack[--sp];
+        const HgNode& n = t.nodes[id];
+        if (n.right == 0) {
+            for (u32 j = 0; j < n.count; j++) {
+                const RtSamplePoint& p = ti.sample_points[t.order[n.first + j]];
+                V3 dpos = ld3(p.position) - hit_point;
+                sum = sum + eval_bssrdf(s, fudge, sqrtf(dot(dpos, dpos))) * ld3(p.payload);
+            }
+            if (pairs) *pairs += n.count;
+            continue;
+        }
+        V3 d = ld3(n.centre) - hit_point;
+        float d2 = dot(d, d);
+        if (d2 > n.radius2 && (float) n.count * mean_area < s.hg_max_solid_angle * d2) {
+            sum = sum + eval_bssrdf(s, fudge, sqrtf(d2)) * t.sums[id];
+            if (pairs) *pairs += 1;
+        } else { stack[sp++] = n.right; stack[sp++] = id + 1; }
+    }
+    return sum;
+}
+
 // raytracing.hlsl:305-349
 void translucent_chit(const Scene& s, const Geometry& geo, const Hit& h, V3 org, V3 dir, RayPayload& p, u64* pairs) {
     const Instance& inst = s.instances[h.inst];
@@ -620,6 +736,10 @@ void translucent_chit(const Scene& s, const Geometry& geo, const Hit& h, V3 org,
         const TranslucentInstance* ti = NULL;
         if (index < s.slot_to_instance.size() && s.slot_to_instance[index] >= 0) ti = &s.translucent_instances[s.slot_to_instance[index]];
         u32 samples_count = ti ? ti->samples_count : 0;
+        if (s.hg_enabled && ti) {
+            diffuse_irradiance = hg_gather(s, *ti, s.properties_by_slot[index], fudge, hit_point, pairs);
+            samples_count = 0;
+        }
         for (u32 i = 0; i < samples_count; i++) {
             const RtSamplePoint& sp = ti->sample_points[i];
             V3 dpos = ld3(sp.position) - hit_point;
@@ -631,7 +751,7 @@ void translucent_chit(const Scene& s, const Geometry& geo, const Hit& h, V3 org,
             } else bssrdf = eval_bssrdf_dipole(s, radius);
             diffuse_irradiance = diffuse_irradiance + bssrdf * ld3(sp.payload);
         }
-        if (pairs) *pairs += samples_count;
+        if (pairs && !s.hg_enabled) *pairs += samples_count;
         diffuse_irradiance = diffuse_irradiance / (float) (s.g.translucent_accumulator_count + 1u);
     }
     float n = s.g.translucent_refractive_index;
@@ -1087,6 +1207,8 @@ int orc_generate_translucent_samples(orc_scene* o, float radius, uint32_t rng_se
         s.properties_by_slot[ti.slot] = mean_area;
         s.slot_to_instance[ti.slot] = (int) i;
         ti.write_sample_points = ti.sample_points; // clone, raytracing.cpp:607-621
+        hg_build(ti);
+        hg_refresh(ti);
     }
     return 0;
 }
@@ -1097,6 +1219,10 @@ int orc_set_globals(orc_scene* o, const RtGlobals* g) {
 }
 int orc_get_globals(orc_scene* o, RtGlobals* g) { *g = o->s.g; return 0; }
 int orc_set_flags(orc_scene* o, uint32_t flags) { o->s.flags = flags; return 0; }
+int orc_set_gather_mode(orc_scene* o, int hierarchical, float max_solid_angle) {
+    if (hierarchical && !(max_solid_angle >= 0.0f)) return RT_ERR_INVALID;
+    o->s.hg_enabled = hierarchical != 0; o->s.hg_max_solid_angle = max_solid_angle; return 0;
+}
 int orc_set_tile_split(orc_scene* o, uint32_t rank, uint32_t world) { o->s.tile_rank = rank; o->s.tile_world = world ? world : 1; return 0; }
 
 // raytracing.cpp:652-747.  Default (no RT_FLAG_DOUBLE_DISPATCH): probe pass -> copy -> one camera pass.
@@ -1107,6 +1233,7 @@ int orc_dispatch_rays(orc_scene* o) {
     if (collect) probe_pass(s);
     if (s.flags & RT_FLAG_DOUBLE_DISPATCH) camera_pass(s);
     if (collect) for (auto& ti : s.translucent_instances) ti.sample_points = ti.write_sample_points; // raytracing.cpp:723-728
+    if (s.hg_enabled) for (auto& ti : s.translucent_instances) hg_refresh(ti);
     camera_pass(s);
     s.g.accumulator_count += 1;
     s.g.translucent_accumulator_count += ((s.flags & RT_FLAG_COLLECT_SAMPLES) != 0) ? 1u : 0u;

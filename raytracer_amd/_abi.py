@@ -165,6 +165,9 @@ class Backend(object):
     def set_flags(self, flags):
         self._call("set_flags", C.c_uint32(flags))
 
+    def set_gather_mode(self, hierarchical, max_solid_angle=0.0):
+        self._call("set_gather_mode", C.c_int(1 if hierarchical else 0), C.c_float(max_solid_angle))
+
     def set_tile_split(self, rank, world):
         self._call("set_tile_split", C.c_uint32(rank), C.c_uint32(world))
 

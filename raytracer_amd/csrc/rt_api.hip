@@ -68,6 +68,9 @@ struct rt_ctx {
     RtSamplePoint *d_sp_read = nullptr, *d_sp_write = nullptr; float* d_sp_normal = nullptr; u32* d_sp_slice = nullptr;
     TranslucentSlice* d_slices = nullptr; int* d_slot_to_ti = nullptr; u32 slot_count = 0;
     std::vector<TranslucentSlice> slices;
+    // hierarchical gather (rt_set_gather_mode)
+    HgNode* d_hg_nodes = nullptr; float4* d_hg_sums = nullptr; float4* d_hg_pos = nullptr; float4* d_hg_pay = nullptr;
+    u32* d_hg_order = nullptr; HgSlice* d_hg_slices = nullptr; bool hg_enabled = false, hg_built = false; float hg_max_solid_angle = 0.0f;
     // frame state
     RtGlobals g; u32 flags = RT_FLAG_COLLECT_SAMPLES | RT_FLAG_ENABLE_SSS;
     u32 width = 0, height = 0;
@@ -139,6 +142,8 @@ int ensure_path_buffers(rt_ctx* c) {
 void free_sample_points(rt_ctx* c) {
     dev_free(c->d_sp_read); dev_free(c->d_sp_write); dev_free(c->d_sp_normal); dev_free(c->d_sp_slice);
     dev_free(c->d_slices); dev_free(c->d_slot_to_ti);
+    dev_free(c->d_hg_nodes); dev_free(c->d_hg_sums); dev_free(c->d_hg_pos); dev_free(c->d_hg_pay); dev_free(c->d_hg_order); dev_free(c->d_hg_slices);
+    c->hg_built = false;
     c->n_points = 0; c->slot_count = 0; c->slices.clear();
 }
 
@@ -170,6 +175,9 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.accumulator = c->d_accumulator; a.render_target = c->d_render_target;
     a.sp_read = c->d_sp_read; a.sp_write = c->d_sp_write; a.sp_normal = c->d_sp_normal; a.sp_slice = c->d_sp_slice;
     a.n_points = c->n_points;
+    a.hg.nodes = c->d_hg_nodes; a.hg.sums = c->d_hg_sums; a.hg.pos = c->d_hg_pos; a.hg.pay = c->d_hg_pay;
+    a.hg.order = c->d_hg_order; a.hg.slices = c->d_hg_slices; a.hg.max_solid_angle = c->hg_max_solid_angle;
+    a.hg.enabled = (c->hg_enabled && c->hg_built) ? 1u : 0u;
     a.bssrdf_table = c->d_table[c->profile]; a.bssrdf_texels = c->table_texels[c->profile];
 }
 
@@ -521,6 +529,8 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
     return RT_OK;
 }
 
+namespace { int hg_build_all(rt_ctx* c); } // hierarchical gather trees, defined below
+
 int rt_generate_translucent_samples(rt_ctx* c, float radius, uint32_t rng_seed, uint32_t phase_seed, uint32_t* total) {
     if (!c || !total || !(radius > 0.0f)) { set_error("rt_generate_translucent_samples: bad arguments"); return RT_ERR_INVALID; }
     *total = 0;
@@ -620,7 +630,107 @@ int rt_generate_translucent_samples(rt_ctx* c, float radius, uint32_t rng_seed, 
     for (auto p : d_normals) if (p) (void) hipFree(p);
     if (status != RT_OK) { free_sample_points(c); return status; }
     *total = n_total;
+    int hrc = hg_build_all(c); if (hrc) return hrc;
     return ensure_path_buffers(c);
+}
+
+namespace {
+// HG-1..HG-4: Morton order of one instance's points, midpoint tree in preorder, leaves <= 8 points
+u32 hg_spread(u32 x) {
+    x &= 0x3ffu; x = (x | (x << 16)) & 0x030000ffu; x = (x | (x << 8)) & 0x0300f00fu;
+    x = (x | (x << 4)) & 0x030c30c3u; x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+struct HgBuilder {
+    const RtSamplePoint* pts; const u32* order; std::vector<HgNode>* nodes; u32 max_depth;
+    u32 build(u32 first, u32 count, u32 depth) {
+        u32 id = (u32) nodes->size();
+        nodes->push_back(HgNode());
+        if (depth > max_depth) max_depth = depth;
+        double sum[3] = { 0, 0, 0 };
+        for (u32 j = 0; j < count; j++) for (int a = 0; a < 3; a++) sum[a] += (double) pts[order[first + j]].position[a];
+        HgNode n;
+        n.cx = (float) (sum[0] / (double) count); n.cy = (float) (sum[1] / (double) count); n.cz = (float) (sum[2] / (double) count);
+        n.radius2 = 0.0f;
+        for (u32 j = 0; j < count; j++) {
+            const float* p = pts[order[first + j]].position;
+            float dx = p[0] - n.cx, dy = p[1] - n.cy, dz = p[2] - n.cz;
+            float d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 > n.radius2) n.radius2 = d2;
+        }
+        n.first = first; n.count = count; n.right = 0; n.depth = depth;
+        if (count > 8) {
+            u32 half = (count + 1) / 2;
+            build(first, half, depth + 1);
+            n.right = build(first + half, count - half, depth + 1);
+        }
+        (*nodes)[id] = n;
+        return id;
+    }
+};
+
+int hg_build_all(rt_ctx* c) {
+    c->hg_built = false;
+    if (c->n_points == 0) return RT_OK;
+    std::vector<RtSamplePoint> pts(c->n_points);
+    RT_HIP(hipMemcpy(pts.data(), c->d_sp_read, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToHost));
+    std::vector<HgNode> nodes; std::vector<HgSlice> hs(c->slices.size());
+    std::vector<u32> order(c->n_points); std::vector<float4> pos(c->n_points);
+    for (size_t si = 0; si < c->slices.size(); si++) {
+        const TranslucentSlice& sl = c->slices[si];
+        hs[si].node_offset = (u32) nodes.size(); hs[si].node_count = 0; hs[si].max_depth = 0; hs[si].pad = 0;
+        if (!sl.count) continue;
+        const RtSamplePoint* p = pts.data() + sl.offset;
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; a++) { lo[a] = p[0].position[a]; hi[a] = p[0].position[a]; }
+        for (u32 k = 1; k < sl.count; k++) for (int a = 0; a < 3; a++) {
+            lo[a] = fminf(lo[a], p[k].position[a]); hi[a] = fmaxf(hi[a], p[k].position[a]);
+        }
+        std::vector<std::pair<u32, u32>> keyed(sl.count);
+        for (u32 k = 0; k < sl.count; k++) {
+            u32 q[3];
+            for (int a = 0; a < 3; a++) {
+                float e = hi[a] - lo[a];
+                q[a] = e > 0.0f ? (u32) fminf(fmaxf((p[k].position[a] - lo[a]) / e * 1024.0f, 0.0f), 1023.0f) : 0u;
+            }
+            keyed[k] = std::make_pair(hg_spread(q[0]) | (hg_spread(q[1]) << 1) | (hg_spread(q[2]) << 2), k);
+        }
+        std::sort(keyed.begin(), keyed.end());
+        u32* ord = order.data() + sl.offset;
+        for (u32 k = 0; k < sl.count; k++) {
+            ord[k] = keyed[k].second;
+            const float* q = p[ord[k]].position;
+            pos[sl.offset + k] = make_float4(q[0], q[1], q[2], 0.0f);
+        }
+        std::vector<HgNode> local;
+        HgBuilder b { p, ord, &local, 0 };
+        b.build(0, sl.count, 0);
+        if (b.max_depth > 22) { set_error("hierarchical gather: tree of instance %zu is %u levels deep", si, b.max_depth); return RT_ERR_LIMIT; }
+        hs[si].node_count = (u32) local.size(); hs[si].max_depth = b.max_depth;
+        nodes.insert(nodes.end(), local.begin(), local.end());
+    }
+    if (nodes.empty()) return RT_OK;
+    RT_HIP(hipMalloc(&c->d_hg_nodes, sizeof(HgNode) * nodes.size()));
+    RT_HIP(hipMalloc(&c->d_hg_sums, sizeof(float4) * nodes.size()));
+    RT_HIP(hipMalloc(&c->d_hg_pos, sizeof(float4) * c->n_points));
+    RT_HIP(hipMalloc(&c->d_hg_pay, sizeof(float4) * c->n_points));
+    RT_HIP(hipMalloc(&c->d_hg_order, 4 * (size_t) c->n_points));
+    RT_HIP(hipMalloc(&c->d_hg_slices, sizeof(HgSlice) * hs.size()));
+    RT_HIP(hipMemcpy(c->d_hg_nodes, nodes.data(), sizeof(HgNode) * nodes.size(), hipMemcpyHostToDevice));
+    RT_HIP(hipMemset(c->d_hg_sums, 0, sizeof(float4) * nodes.size()));
+    RT_HIP(hipMemcpy(c->d_hg_pos, pos.data(), sizeof(float4) * c->n_points, hipMemcpyHostToDevice));
+    RT_HIP(hipMemset(c->d_hg_pay, 0, sizeof(float4) * c->n_points));
+    RT_HIP(hipMemcpy(c->d_hg_order, order.data(), 4 * (size_t) c->n_points, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(c->d_hg_slices, hs.data(), sizeof(HgSlice) * hs.size(), hipMemcpyHostToDevice));
+    c->hg_built = true;
+    return RT_OK;
+}
+} // namespace
+
+int rt_set_gather_mode(rt_ctx* c, int hierarchical, float max_solid_angle) {
+    if (!c || (hierarchical && !(max_solid_angle >= 0.0f))) { set_error("rt_set_gather_mode: bad arguments"); return RT_ERR_INVALID; }
+    c->hg_enabled = hierarchical != 0; c->hg_max_solid_angle = max_solid_angle;
+    return RT_OK;
 }
 
 int rt_set_globals(rt_ctx* c, const RtGlobals* g) {
@@ -649,9 +759,16 @@ int rt_dispatch_rays(rt_ctx* c) {
     RT_HIP(hipSetDevice(c->device));
     int rc = ensure_path_buffers(c); if (rc) return rc;
     bool collect = (c->flags & RT_FLAG_COLLECT_SAMPLES) && c->n_points > 0;
+    auto refresh_hg = [&]() -> int { // node sums of the payloads the camera pass is about to read
+        if (!(c->hg_enabled && c->hg_built)) return RT_OK;
+        PassArgs a; fill_pass_args(c, a, false);
+        return launch_hg_sums(c->stream, a, (u32) c->slices.size());
+    };
     if (collect) { rc = run_pass(c, true); if (rc) return rc; }                       // raytracing.cpp:677-687
+    if (c->flags & RT_FLAG_DOUBLE_DISPATCH) { rc = refresh_hg(); if (rc) return rc; }
     if (c->flags & RT_FLAG_DOUBLE_DISPATCH) { rc = run_pass(c, false); if (rc) return rc; } // :688-695
     if (collect) RT_HIP(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream)); // :723-728
+    rc = refresh_hg(); if (rc) return rc;
     rc = run_pass(c, false); if (rc) return rc;                                       // :734-741
     c->g.accumulator_count += 1;                                                      // :744
     c->g.translucent_accumulator_count += (c->flags & RT_FLAG_COLLECT_SAMPLES) ? 1u : 0u; // :745

@@ -85,6 +85,20 @@ struct PathState {
 };
 struct GatherQueue { u32* path; float *hx, *hy, *hz, *tf, *kx, *ky, *kz; int* ti; };
 
+// hierarchical gather (rt_set_gather_mode): per-instance tree over the sample points, DESIGN.md section 8
+struct alignas(16) HgNode { float cx, cy, cz, radius2; u32 first, count, right, depth; }; // first: within the slice
+struct HgSlice { u32 node_offset, node_count, max_depth, pad; };
+struct HgView {
+    const HgNode* nodes;      // all slices concatenated; child links are relative to the slice's node_offset
+    float4* sums;             // per node: sum of payloads (refreshed by k_hg_sums)
+    const float4* pos;        // per point, sorted order (same offsets as the slices of the sample-point arrays)
+    float4* pay;              // per point, sorted order, refreshed by k_hg_sums
+    const u32* order;         // sorted position -> index in generation order (within the slice)
+    const HgSlice* slices;
+    float max_solid_angle;
+    u32 enabled;
+};
+
 struct DeviceStats { // lives in device memory
     unsigned long long rays_camera, rays_probe, gather_pairs, nodes, tris, insts, node_trips, tri_trips, inst_trips, max_ray_steps;
 };
@@ -119,6 +133,7 @@ struct PassArgs {
     const float* sp_normal;      // 3 per point
     const u32* sp_slice;         // per point -> slice index
     u32 n_points;
+    HgView hg;
     const float* bssrdf_table;   // rgb interleaved
     int bssrdf_texels;
 };
@@ -129,6 +144,7 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
 // fused: finished camera paths resolve their pixel in the shade kernel (no launch_camera_resolve afterwards)
 int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index, bool primary, bool fused);
 int launch_gather(hipStream_t s, const PassArgs& a);
+int launch_hg_sums(hipStream_t s, const PassArgs& a, u32 n_slices); // refresh HgView::pay / sums from sp_read
 int launch_camera_resolve(hipStream_t s, const PassArgs& a);
 int launch_probe_resolve(hipStream_t s, const PassArgs& a);
 int launch_fill_capture(hipStream_t s, const PassArgs& a);

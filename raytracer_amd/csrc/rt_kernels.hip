@@ -493,6 +493,121 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
     if ((threadIdx.x & 63u) == 0 && pairs) atomicAdd(&a.stats->gather_pairs, (unsigned long long) pairs);
 }
 
+// ---- hierarchical gather (rt_set_gather_mode) ----------------------------------------
+// one workgroup per translucent instance: payloads into sorted order, then node sums from the deepest level up
+__global__ __launch_bounds__(SEG) void k_hg_sums(PassArgs a) {
+    const TranslucentSlice sl = a.shade.slices[blockIdx.x];
+    const HgSlice hs = a.hg.slices[blockIdx.x];
+    const RtSamplePoint* pts = a.sp_read + sl.offset;
+    float4* pay = a.hg.pay + sl.offset;
+    const u32* order = a.hg.order + sl.offset;
+    for (u32 j = threadIdx.x; j < sl.count; j += SEG) {
+        const RtSamplePoint& p = pts[order[j]];
+        pay[j] = make_float4(p.payload[0], p.payload[1], p.payload[2], 0.0f);
+    }
+    __syncthreads();
+    const HgNode* nodes = a.hg.nodes + hs.node_offset;
+    float4* sums = a.hg.sums + hs.node_offset;
+    for (int depth = (int) hs.max_depth; depth >= 0; depth--) {
+        for (u32 k = threadIdx.x; k < hs.node_count; k += SEG) {
+            const HgNode n = nodes[k];
+            if ((int) n.depth != depth) continue;
+            f3 sum = mk3(0.0f, 0.0f, 0.0f);
+            if (n.right == 0u) {
+                for (u32 j = 0; j < n.count; j++) { float4 w = pay[n.first + j]; sum = sum + mk3(w.x, w.y, w.z); }
+            } else {
+                float4 l = sums[k + 1u], r = sums[n.right];
+                sum = mk3(l.x, l.y, l.z) + mk3(r.x, r.y, r.z);
+            }
+            sums[k] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+        }
+        __threadfence_block();
+        __syncthreads(); // the next level reads these sums
+    }
+}
+
+static constexpr int HG_STACK = 24; // the walk holds at most depth + 1 entries; depth <= 22 is checked on the host
+
+// MODE as in k_gather.  One hit per lane, per-lane preorder walk with the stack in LDS.
+template <int MODE>
+__global__ __launch_bounds__(GATHER_BLOCK) void k_gather_hg(PassArgs a) {
+    __shared__ float4 s_tab[GATHER_TABLE_MAX];
+    __shared__ u32 s_stack[HG_STACK * GATHER_BLOCK];
+    const u32 n_items = a.goff[a.n_segments];
+    if (blockIdx.x * GATHER_BLOCK >= n_items) return; // uniform
+    const u32 j = blockIdx.x * GATHER_BLOCK + threadIdx.x;
+    const bool active = j < n_items;
+    u32 i;
+    {
+        const u32 jj = active ? j : n_items - 1u;
+        u32 lo = 0, hi = a.n_segments;
+        while (hi - lo > 1u) { u32 mid = (lo + hi) >> 1; if (a.goff[mid] <= jj) lo = mid; else hi = mid; }
+        i = lo * SEG + (jj - a.goff[lo]);
+    }
+    if (MODE == 1) {
+        for (int t = threadIdx.x; t < a.bssrdf_texels; t += GATHER_BLOCK)
+            s_tab[t] = make_float4(a.bssrdf_table[3 * t], a.bssrdf_table[3 * t + 1], a.bssrdf_table[3 * t + 2], 0.0f);
+        __syncthreads();
+    }
+    if (!active) return;
+    const GatherQueue& g = a.gq;
+    const f3 hit = mk3(g.hx[i], g.hy[i], g.hz[i]);
+    const int ti = g.ti[i];
+    const TranslucentSlice sl = a.shade.slices[ti];
+    const HgSlice hs = a.hg.slices[ti];
+    const HgNode* nodes = a.hg.nodes + hs.node_offset;
+    const float4* sums = a.hg.sums + hs.node_offset;
+    const float4* pos = a.hg.pos + sl.offset;
+    const float4* pay = a.hg.pay + sl.offset;
+    const float scale = a.g.translucent_bssrdf_scale, z = scale * scale;
+    const float eta = a.g.translucent_refractive_index;
+    DipoleConst cr = dipole_constants(a.g.translucent_scattering[0], a.g.translucent_absorption[0], eta);
+    DipoleConst cg = dipole_constants(a.g.translucent_scattering[1], a.g.translucent_absorption[1], eta);
+    DipoleConst cb = dipole_constants(a.g.translucent_scattering[2], a.g.translucent_absorption[2], eta);
+    auto bssrdf = [&](float radius) -> f3 {
+        if (MODE != 0) {
+            f3 tv = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, radius / scale)
+                              : sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, radius / scale);
+            return (a.fudge * tv) / z;
+        }
+        return mk3(dipole_eval(cr, radius), dipole_eval(cg, radius), dipole_eval(cb, radius));
+    };
+    f3 E = mk3(0.0f, 0.0f, 0.0f);
+    u32 terms = 0;
+    u32* stack = s_stack + threadIdx.x;
+    int sp = 0;
+    if (hs.node_count) stack[(sp++) * GATHER_BLOCK] = 0u;
+    while (sp > 0) {
+        const u32 id = stack[(--sp) * GATHER_BLOCK];
+        const HgNode n = nodes[id];
+        if (n.right == 0u) {
+            for (u32 k = 0; k < n.count; k++) {
+                const float4 p = pos[n.first + k], w = pay[n.first + k];
+                f3 dp = mk3(p.x, p.y, p.z) - hit;
+                E = E + bssrdf(sqrtf(dot3(dp, dp))) * mk3(w.x, w.y, w.z);
+            }
+            terms += n.count;
+            continue;
+        }
+        f3 d = mk3(n.cx, n.cy, n.cz) - hit;
+        float d2 = dot3(d, d);
+        if (d2 > n.radius2 && (float) n.count * sl.mean_area < a.hg.max_solid_angle * d2) {
+            const float4 w = sums[id];
+            E = E + bssrdf(sqrtf(d2)) * mk3(w.x, w.y, w.z);
+            terms += 1u;
+        } else if (sp + 2 <= HG_STACK) {
+            stack[(sp++) * GATHER_BLOCK] = n.right;
+            stack[(sp++) * GATHER_BLOCK] = id + 1u;
+        }
+    }
+    E = E / (float) (a.g.translucent_accumulator_count + 1u);                                           // :332
+    f3 emission = E * g.tf[i] / (RT_TAU_F / 2.0f);                                                     // :347
+    f3 k3 = mk3(g.kx[i], g.ky[i], g.kz[i]);
+    const u32 path = g.path[i];
+    a.ps.rad_x[path] += emission.x * k3.x; a.ps.rad_y[path] += emission.y * k3.y; a.ps.rad_z[path] += emission.z * k3.z;
+    atomicAdd(&a.stats->gather_pairs, (unsigned long long) terms);
+}
+
 __global__ __launch_bounds__(BT) void k_fill_capture(RtHit* capture, size_t n) {
     size_t i = (size_t) blockIdx.x * BT + threadIdx.x;
     if (i >= n) return;
@@ -541,9 +656,22 @@ int launch_gather(hipStream_t s, const PassArgs& a) {
     if (!n) return RT_OK;
     hipLaunchKernelGGL(k_gather_offsets, dim3(1), dim3(SEG), 0, s, a);
     dim3 grid = blocks(n, GATHER_BLOCK), block(GATHER_BLOCK);
+    if (a.hg.enabled) {
+        if (a.g.translucent_bssrdf_scale == 0.0f) hipLaunchKernelGGL(k_gather_hg<0>, grid, block, 0, s, a);
+        else if (a.bssrdf_texels <= GATHER_TABLE_MAX) hipLaunchKernelGGL(k_gather_hg<1>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(k_gather_hg<2>, grid, block, 0, s, a);
+        RT_HIP(hipGetLastError());
+        return RT_OK;
+    }
     if (a.g.translucent_bssrdf_scale == 0.0f) hipLaunchKernelGGL(k_gather<0>, grid, block, 0, s, a); // raytracing.hlsl:316-320
     else if (a.bssrdf_texels <= GATHER_TABLE_MAX) hipLaunchKernelGGL(k_gather<1>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(k_gather<2>, grid, block, 0, s, a);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+int launch_hg_sums(hipStream_t s, const PassArgs& a, u32 n_slices) {
+    if (!n_slices || !a.hg.enabled) return RT_OK;
+    hipLaunchKernelGGL(k_hg_sums, dim3(n_slices), dim3(SEG), 0, s, a);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

@@ -23,6 +23,7 @@ class SceneDesc(object):
         self.sample_radius = None   # set => generate_translucent_samples(radius, rng_seed, phase_seed)
         self.rng_seed, self.phase_seed = 1, 2
         self.bssrdf_profile = 0
+        self.gather_mode = None     # (hierarchical, max_solid_angle) => set_gather_mode; None = the reference's loop
         self.frames = 1
 
     def triangle_count(self):
@@ -37,6 +38,8 @@ class SceneDesc(object):
         backend.set_flags(self.flags | extra_flags)
         backend.set_bssrdf_profile(self.bssrdf_profile)
         backend.set_globals(self.globals)
+        if self.gather_mode is not None:
+            backend.set_gather_mode(*self.gather_mode)
         points = 0
         if self.sample_radius is not None:
             points = backend.generate_translucent_samples(self.sample_radius, self.rng_seed, self.phase_seed)

@@ -102,3 +102,46 @@ def test_sss_disabled_and_collection_disabled(oracle_mod):
         assert gpu.get_stats()["gather_pairs"] == 0
     finally:
         gpu.close(); cpu.close()
+
+
+# ---- hierarchical gather (rt_set_gather_mode) --------------------------------
+@pytest.mark.parametrize("tabulated,limit", [(True, 0.05), (False, 0.05), (True, 0.5)])
+def test_hierarchical_gather_matches_the_oracle(oracle_mod, tabulated, limit):
+    """same tree, same walk, same arithmetic on both sides: to the north-star tolerance (in practice bit for bit)"""
+    s = scenes.cornell_bunny(96, 54, spp=2, bounces=2, tabulated=tabulated, sample_radius=0.03)
+    s.gather_mode = (True, limit)
+    _check_translucent(s, oracle_mod, frames=2)
+
+
+def test_hierarchical_gather_two_instances_double_dispatch(oracle_mod):
+    s = scenes.cornell(96, 54, spp=1, bounces=3, translucent_boxes=True, sample_radius=0.02)
+    s.gather_mode = (True, 0.1)
+    s.flags |= _abi.RT_FLAG_DOUBLE_DISPATCH
+    _check_translucent(s, oracle_mod, frames=2)
+
+
+def test_hierarchical_gather_against_the_exact_sum():
+    """limit 0 visits every point (only the order of the float sum differs from the reference loop: 1e-4); a useful
+    limit stays close to the exact image and evaluates several times fewer terms"""
+    from raytracer_amd import api
+    images, terms = {}, {}
+    for name, mode in [("exact", None), ("all", (True, 0.0)), ("approx", (True, 0.5))]:
+        s = scenes.cornell_bunny(128, 72, spp=2, bounces=2, sample_radius=0.02)
+        s.gather_mode = mode
+        rt = api.Raytracer(0)
+        try:
+            s.setup(rt)
+            from raytracer_amd import distributed
+            for f in range(2):
+                distributed.render_frame(rt, s.globals, f, 7)
+            images[name] = rt.read_accumulator()
+            terms[name] = rt.get_stats()["gather_pairs"]
+        finally:
+            rt.close()
+    pu.compare_images(images["all"], images["exact"])
+    assert terms["all"] == terms["exact"]
+    err = images["approx"].astype(np.float64) - images["exact"].astype(np.float64)
+    rmse = float(np.sqrt(np.mean(err ** 2)))
+    print("hierarchical gather, limit 0.5 sr: %.1fx fewer terms, image RMSE %.2e" % (terms["exact"] / terms["approx"], rmse))
+    assert rmse < 1e-2
+    assert terms["approx"] * 2 < terms["exact"]

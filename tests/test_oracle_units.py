@@ -237,3 +237,23 @@ def test_oracle_threads_do_not_change_results(oracle_mod):
     a.dispatch_rays(); b.dispatch_rays()
     assert a.read_accumulator().tobytes() == b.read_accumulator().tobytes()
     a.close(); b.close()
+
+
+def test_oracle_hierarchical_gather_limit_zero_is_the_exact_sum(oracle_mod):
+    """HG with a zero solid-angle limit walks every leaf: the same terms as translucent_chit's loop in another order"""
+    from raytracer_amd import scenes
+    import parity_util as pu
+    images = []
+    for mode in (None, (True, 0.0), (True, 0.2)):
+        s = scenes.cornell_bunny(24, 16, spp=1, bounces=1, sample_radius=0.08)
+        s.gather_mode = mode
+        cpu = oracle_mod.Oracle(brute_force=False, threads=4)
+        try:
+            s.setup(cpu)
+            for _ in range(2):
+                cpu.dispatch_rays()
+            images.append(cpu.read_accumulator())
+        finally:
+            cpu.close()
+    pu.compare_images(images[1], images[0])
+    assert np.isfinite(images[2]).all() and np.abs(images[2] - images[0]).max() < 0.1
