@@ -8,6 +8,7 @@
 // and no inter-workgroup hand-off inside a launch: every step is its own kernel and numbering comes from prefix
 // scans, which also makes the tree bit-reproducible from run to run.
 #include "rt_internal.h"
+#include <stdlib.h>
 
 namespace rti {
 
@@ -15,7 +16,7 @@ using namespace rtd;
 
 static constexpr int BT = 256;
 static constexpr int SCAN_BLOCK = 1024;
-static constexpr int PLOC_RADIUS = 8;
+static int ploc_radius() { static int r = [] { const char* v = getenv("RT_PLOC_RADIUS"); int x = v ? atoi(v) : 8; return x < 1 ? 1 : (x > 256 ? 256 : x); }(); return r; }
 static inline dim3 grid_for(u32 n, int bt = BT) { return dim3((n + bt - 1) / bt); }
 
 #define RT_SAH_NODE 1.0f
@@ -38,12 +39,12 @@ __global__ void k_ploc_init(const Aabb* __restrict__ boxes, const u32* __restric
     cbox[i] = boxes[vals[i]];
 }
 
-// nearest neighbour by merged surface area within +-PLOC_RADIUS positions (ties: the lower position)
-__global__ void k_ploc_nn(const Aabb* __restrict__ cbox, u32 m, int* __restrict__ nn) {
+// nearest neighbour by merged surface area within +-radius positions (ties: the lower position)
+__global__ void k_ploc_nn(const Aabb* __restrict__ cbox, u32 m, int radius, int* __restrict__ nn) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int) m) return;
     Aabb me = cbox[i];
-    int j0 = i - PLOC_RADIUS < 0 ? 0 : i - PLOC_RADIUS, j1 = i + PLOC_RADIUS >= (int) m ? (int) m - 1 : i + PLOC_RADIUS;
+    int j0 = i - radius < 0 ? 0 : i - radius, j1 = i + radius >= (int) m ? (int) m - 1 : i + radius;
     float best = 3.4e38f; int bj = -1;
     for (int j = j0; j <= j1; j++) {
         if (j == i) continue;
@@ -222,7 +223,7 @@ int ploc_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace& pw, u32 n, int le
     for (int iter = 0; m > 1; iter++) {
         if (iter > 4096) { set_error("ploc_build: no convergence"); return RT_ERR_DEVICE; }
         u32 nblocks = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
-        hipLaunchKernelGGL(k_ploc_nn, grid_for(m), dim3(BT), 0, s, pw.cbox[cur], m, pw.nn);
+        hipLaunchKernelGGL(k_ploc_nn, grid_for(m), dim3(BT), 0, s, pw.cbox[cur], m, ploc_radius(), pw.nn);
         hipLaunchKernelGGL(k_ploc_scan_block, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, pw.nn, m, pw.excl, pw.sums);
         hipLaunchKernelGGL(k_ploc_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, pw.sums, nblocks, pw.totals);
         hipLaunchKernelGGL(k_ploc_apply, grid_for(m), dim3(BT), 0, s, pw.cid[cur], pw.cbox[cur], pw.nn, m, pw.excl, pw.sums, node_base,
