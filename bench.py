@@ -138,6 +138,15 @@ def main():
     for _ in range(args.warmup):
         step(False)
     rt.sync()
+    if dist is not None:
+        # the first collective builds the communicator (RCCL rings over xGMI): untimed, like the other warm-up work
+        scratch = torch.zeros_like(acc)
+        if args.rehearse:
+            dist.all_reduce(scratch, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce(scratch, dst=0, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        del scratch
     rt.set_flags(scene.flags | _abi.RT_FLAG_TIME_KERNELS)
     rt.reset_stats()
 
