@@ -53,6 +53,7 @@ void rt_default_globals(float aspect, RtGlobals* g);
 uint32_t rt_next_frame_rng(uint32_t frame_rng);
 
 /* image output (stands in for stbi_write_png, main.cpp:750) */
+int rt_write_png(const char* filename, const uint8_t* rgba8, uint32_t width, uint32_t height); /* 8-bit RGBA like main.cpp:750 */
 int rt_write_ppm(const char* filename, const uint8_t* rgba8, uint32_t width, uint32_t height);
 int rt_write_pfm(const char* filename, const float* rgba, uint32_t width, uint32_t height, float scale);
 

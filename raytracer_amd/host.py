@@ -86,6 +86,12 @@ def load_skin_table(profile):
     return np.fromfile(data_path("skin_%d.f32" % profile), dtype="<f4").reshape(3, -1)
 
 
+def write_png(filename, rgba8):
+    h, w = rgba8.shape[:2]
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    return _lib.rt_write_png(filename.encode(), C.c_void_p(a.ctypes.data), C.c_uint32(w), C.c_uint32(h))
+
+
 def write_ppm(filename, rgba8):
     h, w = rgba8.shape[:2]
     a = np.ascontiguousarray(rgba8, dtype=np.uint8)

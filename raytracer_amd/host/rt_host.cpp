@@ -3,6 +3,7 @@
 // without Win32 or DirectXMath; see include/rt_host.h for the per-function citations.
 #include "../../include/rt_host.h"
 
+#include <algorithm>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -255,6 +256,60 @@ int rt_write_ppm(const char* filename, const uint8_t* rgba8, uint32_t width, uin
     for (size_t i = 0; i < (size_t) width * height; i++) fwrite(rgba8 + 4 * i, 1, 3, f);
     fclose(f);
     return RT_OK;
+}
+
+// PNG, 8-bit RGBA, what stbi_write_png(filename, w, h, 4, data, pitch) produces at main.cpp:750 up to the choice of
+// compression: the zlib stream here uses stored (uncompressed) deflate blocks, so no compressor is needed
+namespace {
+uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n) {
+    static uint32_t table[256]; static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+        ready = true;
+    }
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    return crc;
+}
+void put_be32(std::vector<uint8_t>& v, uint32_t x) { for (int s = 24; s >= 0; s -= 8) v.push_back((uint8_t) (x >> s)); }
+bool write_chunk(FILE* f, const char type[4], const std::vector<uint8_t>& data) {
+    std::vector<uint8_t> head; put_be32(head, (uint32_t) data.size());
+    uint32_t crc = crc32_update(0xffffffffu, (const uint8_t*) type, 4);
+    if (!data.empty()) crc = crc32_update(crc, data.data(), data.size());
+    std::vector<uint8_t> tail; put_be32(tail, crc ^ 0xffffffffu);
+    return fwrite(head.data(), 1, 4, f) == 4 && fwrite(type, 1, 4, f) == 4 &&
+           (data.empty() || fwrite(data.data(), 1, data.size(), f) == data.size()) && fwrite(tail.data(), 1, 4, f) == 4;
+}
+} // namespace
+
+int rt_write_png(const char* filename, const uint8_t* rgba8, uint32_t width, uint32_t height) {
+    if (!filename || !rgba8 || width == 0 || height == 0) return RT_ERR_INVALID;
+    FILE* f = fopen(filename, "wb");
+    if (!f) return RT_ERR_INVALID;
+    static const uint8_t signature[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+    bool ok = fwrite(signature, 1, 8, f) == 8;
+    std::vector<uint8_t> ihdr; put_be32(ihdr, width); put_be32(ihdr, height);
+    ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0); // 8-bit RGBA, no interlace
+    ok = ok && write_chunk(f, "IHDR", ihdr);
+    // raw scanlines: filter byte 0 + row
+    const size_t row = (size_t) width * 4, raw_size = (row + 1) * height;
+    std::vector<uint8_t> raw(raw_size);
+    for (uint32_t y = 0; y < height; y++) { raw[(row + 1) * y] = 0; memcpy(&raw[(row + 1) * y + 1], rgba8 + row * y, row); }
+    uint32_t a = 1, b = 0; // Adler-32 of the raw data
+    for (size_t i = 0; i < raw_size;) { size_t n = std::min<size_t>(raw_size - i, 5552); for (size_t k = 0; k < n; k++) { a += raw[i + k]; b += a; } a %= 65521u; b %= 65521u; i += n; }
+    std::vector<uint8_t> z; z.reserve(raw_size + raw_size / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    for (size_t i = 0; i < raw_size;) {
+        size_t n = std::min<size_t>(raw_size - i, 65535);
+        z.push_back(i + n == raw_size ? 1 : 0); // BFINAL, BTYPE = 00 (stored)
+        z.push_back((uint8_t) (n & 0xff)); z.push_back((uint8_t) (n >> 8));
+        z.push_back((uint8_t) (~n & 0xff)); z.push_back((uint8_t) ((~n >> 8) & 0xff));
+        z.insert(z.end(), raw.begin() + i, raw.begin() + i + n);
+        i += n;
+    }
+    put_be32(z, (b << 16) | a);
+    ok = ok && write_chunk(f, "IDAT", z) && write_chunk(f, "IEND", std::vector<uint8_t>());
+    fclose(f);
+    return ok ? RT_OK : RT_ERR_INVALID;
 }
 
 int rt_write_pfm(const char* filename, const float* rgba, uint32_t width, uint32_t height, float scale) {

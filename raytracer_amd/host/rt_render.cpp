@@ -104,6 +104,7 @@ int main(int argc, char** argv) {
     // file name carries the parameters like the reference's capture (main.cpp:740-750)
     char name[512];
     snprintf(name, sizeof name, "%s_%ux%u_f%u_spp%u_b%u_pts%u", out.c_str(), width, height, frames, spp, bounces, total_points);
+    rt_write_png((std::string(name) + ".png").c_str(), rgba8.data(), width, height);                 // main.cpp:750
     rt_write_ppm((std::string(name) + ".ppm").c_str(), rgba8.data(), width, height);
     rt_write_pfm((std::string(name) + ".pfm").c_str(), acc.data(), width, height, 1.0f / (float) frames);
     printf("%s: %u frames, %u sample points, %llu camera rays, %llu probe rays, %llu gather pairs\n", name, frames, total_points,

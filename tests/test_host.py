@@ -132,3 +132,29 @@ def test_scene_configs_have_the_documented_sizes():
     m = np.array(s5.instances[3][0])
     sc = np.linalg.norm(m[:3, :3], axis=1)
     assert np.allclose(sc, sc[0], rtol=1e-5)      # uniform scale (required by bluenoise.cpp:122-127)
+
+
+def test_png_writer_round_trips_through_zlib(tmp_path):
+    """rt_write_png (main.cpp:750's stbi_write_png): signature, chunk CRCs, IHDR, and the IDAT stream inflates to the
+    filter-0 scanlines of the image"""
+    import struct, zlib
+    from raytracer_amd import host
+    rs = np.random.RandomState(3)
+    img = rs.randint(0, 256, (37, 301, 4)).astype(np.uint8)     # 45 KB raw: one stored block; and a larger one below
+    for image in (img, np.tile(img, (5, 1, 1))):
+        path = str(tmp_path / "a.png")
+        assert host.write_png(path, image) == 0
+        data = open(path, "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, chunks = 8, []
+        while pos < len(data):
+            n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+            body = data[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == (zlib.crc32(kind + body) & 0xffffffff)
+            chunks.append((kind, body)); pos += 12 + n
+        assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+        h, w = image.shape[:2]
+        assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 6, 0, 0, 0)
+        raw = zlib.decompress(chunks[1][1])
+        rows = np.frombuffer(raw, dtype=np.uint8).reshape(h, 1 + 4 * w)
+        assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(h, w, 4), image)
