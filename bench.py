@@ -234,6 +234,10 @@ def main():
                          "model_counts": model, "gpu_bvh_counts": gpu_counts},
             "cpu_baseline": cpu_line,
         }
+        # acceleration-structure builds are outside the timed loop: reported separately
+        out["build"] = {"last_blas_ms": stats["blas_build_ms"], "blas_triangles_total": stats["blas_triangles"],
+                        "tlas_ms": stats["tlas_build_ms"], "tlas_instances": stats["tlas_instances"],
+                        "tlas_Minstances_per_s": stats["tlas_instances"] / (stats["tlas_build_ms"] * 1e-3) / 1e6 if stats["tlas_build_ms"] > 0 else None}
         if stats["gather_launches"] and stats["gather_ms"] > 0:
             # second hot loop: (hit, sample point) pairs of translucent_chit; 24 B per pair from LDS
             pairs_s = stats["gather_pairs"] / (stats["gather_ms"] * 1e-3)

@@ -91,13 +91,18 @@ def geometry_array(geometries):
     return arr, keep
 
 
+INSTANCE_DTYPE = np.dtype([("transform", "<f4", 16), ("blas", "<i4")])
+assert INSTANCE_DTYPE.itemsize == C.sizeof(RtInstance)
+
+
 def instance_array(instances):
-    """instances: list of (transform 4x4 row-major array-like, blas handle)."""
-    arr = (RtInstance * len(instances))()
-    for i, (m, blas) in enumerate(instances):
-        flat = np.asarray(m, dtype=np.float32).reshape(16)
-        arr[i].transform = (C.c_float * 16)(*[float(x) for x in flat])
-        arr[i].blas = int(blas)
+    """instances: list of (transform 4x4 row-major array-like, blas handle) -> ctypes array of RtInstance."""
+    n = len(instances)
+    buf = np.zeros(n, dtype=INSTANCE_DTYPE)
+    if n:
+        buf["transform"] = np.asarray([np.asarray(m, dtype=np.float32).reshape(16) for m, _ in instances], dtype=np.float32)
+        buf["blas"] = np.asarray([int(b) for _, b in instances], dtype=np.int32)
+    arr = (RtInstance * n).from_buffer_copy(buf.tobytes()) if n else (RtInstance * 0)()
     return arr
 
 
