@@ -25,6 +25,7 @@ int main(int argc, char** argv) {
     std::string data = "raytracer_amd/data", out = "render";
     uint32_t width = 1000, height = 955, frames = 16, spp = 1, bounces = 4, seed = 0x12345678; // main.cpp:162-163,413-414
     float radius = 0.025f, tabulated = 0.0f;                                                   // main.cpp:50,418
+    float hg_limit = -1.0f; // >= 0: hierarchical BSSRDF gather with this solid-angle limit (rt_set_gather_mode; not in the reference)
     bool lambert_boxes = false, double_dispatch = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -34,12 +35,14 @@ int main(int argc, char** argv) {
         else if (a == "--frames") frames = (uint32_t) atoi(next()); else if (a == "--spp") spp = (uint32_t) atoi(next());
         else if (a == "--bounces") bounces = (uint32_t) atoi(next()); else if (a == "--radius") radius = (float) atof(next());
         else if (a == "--tabulated") tabulated = (float) atof(next()); else if (a == "--seed") seed = (uint32_t) strtoul(next(), nullptr, 0);
+        else if (a == "--hierarchical-gather") hg_limit = (float) atof(next());
         else if (a == "--lambert-boxes") lambert_boxes = true; else if (a == "--double-dispatch") double_dispatch = true;
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     std::vector<float> skin0 = load_f32(data + "/skin_0.f32"), skin1 = load_f32(data + "/skin_1.f32");
     Raytracing::init(0, skin0.data(), skin1.data(), (uint32_t) (skin0.size() / 3));
     Raytracing::update_resolution(width, height);
+    if (hg_limit >= 0.0f) Raytracing::check(rt_set_gather_mode(Raytracing::ctx(), 1, hg_limit), "rt_set_gather_mode");
 
     // SCENE CREATION, main.cpp:240-361
     float cornell_aabb[6]; rt_aabb_null(cornell_aabb);
