@@ -55,6 +55,7 @@ struct rt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     LbvhWorkspace lbvh; PlocWorkspace ploc; int bvh_builder = 1; float sah_tri = 1.3f; // RT_BVH_BUILDER: 0 LBVH, 1 PLOC; RT_SAH_TRI
+    bool exact_instance_boxes = true; // RT_EXACT_INSTANCE_BOXES=0: TLAS boxes from the corners of the BLAS box (tuning aid)
     std::vector<Blas> blas;
     std::vector<TranslucentMesh> translucent_meshes;
     std::vector<float> translucent_mean_area; // g_translucent_properties
@@ -308,6 +309,7 @@ int rt_create(const int* devices, int n, rt_ctx** out) {
     c->device = devices[0];
     if (const char* v = getenv("RT_BVH_BUILDER")) c->bvh_builder = atoi(v);
     if (const char* v = getenv("RT_SAH_TRI")) c->sah_tri = (float) atof(v);
+    if (const char* v = getenv("RT_EXACT_INSTANCE_BOXES")) c->exact_instance_boxes = atoi(v) != 0;
     RT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     RT_HIP(hipMalloc(&c->d_stats, sizeof(DeviceStats)));
@@ -478,6 +480,7 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
     std::vector<u32> counts(c->blas.size(), 0);
     std::vector<InstRec> rec(n); std::vector<InstShade> shade(n);
     int max_blas_depth = 0;
+    uint64_t vertex_work = 0; // vertices to transform for exact instance boxes
     for (int i = 0; i < n; i++) {
         const Blas& b = c->blas[instances[i].blas];
         counts[instances[i].blas] += 1;
@@ -495,7 +498,8 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
         rec[i].nodes = b.d_nodes; rec[i].tris_offset = (u32) ((const char*) b.d_tris - (const char*) b.d_nodes); rec[i].bound = b.bound;
         memcpy(shade[i].object_to_world, instances[i].transform, 64);
         shade[i].vertices = b.d_verts; shade[i].indices = b.d_indices; shade[i].geoms = b.d_geoms; shade[i].tris = b.d_tris;
-        shade[i].instance_id = instance_id; shade[i]._pad = 0;
+        shade[i].instance_id = instance_id; shade[i].vertex_count = (u32) b.verts.size();
+        vertex_work += b.verts.size();
         max_blas_depth = std::max(max_blas_depth, b.depth);
     }
     dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
@@ -510,7 +514,8 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
     hipEvent_t e0, e1;
     RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
     RT_HIP(hipEventRecord(e0, c->stream));
-    rc = lbvh_instance_boxes(c->stream, c->lbvh, c->d_inst_shade, c->d_inst_rec, (u32) n); if (rc) return rc;
+    const bool exact_boxes = c->exact_instance_boxes && vertex_work <= (4ull << 30);
+    rc = lbvh_instance_boxes(c->stream, c->lbvh, c->d_inst_shade, c->d_inst_rec, (u32) n, exact_boxes); if (rc) return rc;
     rc = lbvh_build(c->stream, c->lbvh, &c->ploc, c->bvh_builder, c->sah_tri, (u32) n, 1, true, c->d_tlas_nodes, c->d_tlas_perm); if (rc) return rc;
     RT_HIP(hipEventRecord(e1, c->stream));
     BvhNode root;

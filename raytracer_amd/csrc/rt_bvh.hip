@@ -26,6 +26,32 @@ __global__ void k_triangle_boxes(const RtVertex* __restrict__ verts, const uint1
     boxes[i] = b;
 }
 
+// world box of an instance from its vertices (one wave per instance): for a rotated mesh this is markedly tighter than
+// the box of the eight transformed corners of the object-space box, so neighbouring instances overlap less in the TLAS
+__global__ __launch_bounds__(64) void k_instance_boxes_exact(const InstShade* __restrict__ shade, u32 n, Aabb* __restrict__ boxes) {
+    const u32 i = blockIdx.x;
+    if (i >= n) return;
+    const InstShade& in = shade[i];
+    float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+    for (u32 j = threadIdx.x; j < in.vertex_count; j += 64u) {
+        const float* p = in.vertices[j].position;
+        f3 w = xform_point44(in.object_to_world, mk3(p[0], p[1], p[2]));
+        float wv[3] = { w.x, w.y, w.z };
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], wv[k]); hi[k] = fmaxf(hi[k], wv[k]); }
+    }
+    for (int off = 32; off >= 1; off >>= 1)
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
+    if (threadIdx.x == 0) {
+        float amax = 0.0f;
+        for (int k = 0; k < 3; k++) amax = fmaxf(amax, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+        // the world-space box test and the object-space triangle test round differently: pad generously
+        float pad = amax * 1.0e-5f + 1.0e-30f;
+        Aabb b;
+        for (int k = 0; k < 3; k++) { b.lo[k] = lo[k] - pad; b.hi[k] = hi[k] + pad; }
+        boxes[i] = b;
+    }
+}
+
 __global__ void k_instance_boxes(const InstShade* __restrict__ shade, const InstRec* __restrict__ insts, u32 n,
                                  Aabb* __restrict__ boxes) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -233,9 +259,10 @@ int lbvh_triangle_boxes(hipStream_t s, LbvhWorkspace& w, const RtVertex* verts, 
     return RT_OK;
 }
 
-int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const InstShade* shade, const InstRec* insts, u32 n) {
+int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const InstShade* shade, const InstRec* insts, u32 n, bool exact) {
     if (n == 0) return RT_OK;
-    hipLaunchKernelGGL(k_instance_boxes, grid_for(n), dim3(BT), 0, s, shade, insts, n, w.boxes);
+    if (exact) hipLaunchKernelGGL(k_instance_boxes_exact, dim3(n), dim3(64), 0, s, shade, n, w.boxes);
+    else hipLaunchKernelGGL(k_instance_boxes, grid_for(n), dim3(BT), 0, s, shade, insts, n, w.boxes);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

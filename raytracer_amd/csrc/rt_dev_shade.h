@@ -24,7 +24,7 @@ struct InstShade {
     const GeomRec*  geoms;
     const TriRec*   tris;
     u32 instance_id;           // InstanceID()
-    u32 _pad;
+    u32 vertex_count;          // of `vertices`
 };
 
 // one translucent instance's slice of the concatenated sample-point arrays

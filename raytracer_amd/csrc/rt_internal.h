@@ -64,7 +64,8 @@ int ploc_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace& pw, u32 n, int le
 // boxes for the n triangles of a BLAS -> w.boxes
 int lbvh_triangle_boxes(hipStream_t s, LbvhWorkspace& w, const RtVertex* verts, const uint16_t* indices, u32 n_tris);
 // world boxes of n instances (8 corners of each BLAS root box through object_to_world, padded) -> w.boxes
-int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const rtd::InstShade* shade, const rtd::InstRec* insts, u32 n);
+// exact: boxes from every vertex of the instance's BLAS (tighter); otherwise from the corners of its object-space box
+int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const rtd::InstShade* shade, const rtd::InstRec* insts, u32 n, bool exact);
 // builds the hierarchy over w.boxes[0..n); nodes_out has max(1, n-1) entries; perm_out[n] = sorted -> original.
 // builder: 0 = Karras LBVH hierarchy, 1 = PLOC agglomerative clustering (pw required)
 // sah_tri: cost of one triangle test relative to one two-child node step in the surface-area heuristic
