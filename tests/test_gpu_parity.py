@@ -100,3 +100,17 @@ def test_many_instances_of_tiny_blas(oracle_mod):
     s.instances = [(host.affine_transform(float(rs.uniform(0.02, 0.06)), float(rs.uniform(0, 6.28)),
                                           tuple(rs.uniform(-0.7, 0.7, 3))), 0) for _ in range(1500)] + [s.instances[1]]
     _check_scene(s, oracle_mod, frames=1, brute_force=True)
+
+
+@pytest.mark.parametrize("builder", ["0", "1"])
+def test_both_bvh_builders_give_the_same_hits(oracle_mod, monkeypatch, builder):
+    """the closest hit does not depend on the tree (S5): Karras LBVH (0) and PLOC (1, default) against brute force"""
+    monkeypatch.setenv("RT_BVH_BUILDER", builder)       # read at rt_create
+    _check_scene(scenes.bunny(96, 54, spp=1, bounces=3), oracle_mod)
+    _check_scene(scenes.bunny_field(96, 54, spp=1, bounces=2, grid=8, count=40), oracle_mod, brute_force=False)
+
+
+def test_corner_instance_boxes_still_work(oracle_mod, monkeypatch):
+    """TLAS boxes from the corners of the BLAS box (the fallback for very large vertex counts)"""
+    monkeypatch.setenv("RT_EXACT_INSTANCE_BOXES", "0")
+    _check_scene(scenes.bunny_field(96, 54, spp=1, bounces=2, grid=8, count=40), oracle_mod, brute_force=False)
