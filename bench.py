@@ -190,7 +190,7 @@ def main():
         gpu_counts = {"n_node": cs["nodes_visited"] / crays, "n_tri": cs["tris_tested"] / crays, "n_inst": cs["instances_entered"] / crays}
 
         cpu_line, model = None, None
-        if not args.no_cpu and world >= 1:
+        if not args.no_cpu and world == 1:  # the CPU baseline is reported at N = 1 only
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
             cpu_line, model = cpu_baseline(scene, args.cpu_seconds, threads)
         if model is None:
