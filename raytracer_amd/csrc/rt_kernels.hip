@@ -433,6 +433,9 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
     DipoleConst cr = dipole_constants(a.g.translucent_scattering[0], a.g.translucent_absorption[0], eta);
     DipoleConst cg = dipole_constants(a.g.translucent_scattering[1], a.g.translucent_absorption[1], eta);
     DipoleConst cb = dipole_constants(a.g.translucent_scattering[2], a.g.translucent_absorption[2], eta);
+    // the shipped defaults use one scattering / absorption pair for all channels (main.cpp:420-422): evaluate once
+    const bool grey = a.g.translucent_scattering[0] == a.g.translucent_scattering[1] && a.g.translucent_scattering[0] == a.g.translucent_scattering[2] &&
+                      a.g.translucent_absorption[0] == a.g.translucent_absorption[1] && a.g.translucent_absorption[0] == a.g.translucent_absorption[2];
     f3 E = mk3(0.0f, 0.0f, 0.0f);
     u32 pairs = 0;
     // translucent instances present in this workgroup, in increasing index order
@@ -470,7 +473,8 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
                     f3 tv = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, radius / scale)
                                       : sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, radius / scale);
                     bs = (a.fudge * tv) / z;                                                                 // :272-276
-                } else bs = mk3(dipole_eval(cr, radius), dipole_eval(cg, radius), dipole_eval(cb, radius));  // :278-301
+                } else if (grey) { float v = dipole_eval(cr, radius); bs = mk3(v, v, v); }                    // :278-301
+                else bs = mk3(dipole_eval(cr, radius), dipole_eval(cg, radius), dipole_eval(cb, radius));
                 return bs * mk3(gp.wx, gp.wy, gp.wz);
             };
             u32 k = 0;
@@ -564,12 +568,16 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather_hg(PassArgs a) {
     DipoleConst cr = dipole_constants(a.g.translucent_scattering[0], a.g.translucent_absorption[0], eta);
     DipoleConst cg = dipole_constants(a.g.translucent_scattering[1], a.g.translucent_absorption[1], eta);
     DipoleConst cb = dipole_constants(a.g.translucent_scattering[2], a.g.translucent_absorption[2], eta);
+    // the shipped defaults use one scattering / absorption pair for all channels (main.cpp:420-422): evaluate once
+    const bool grey = a.g.translucent_scattering[0] == a.g.translucent_scattering[1] && a.g.translucent_scattering[0] == a.g.translucent_scattering[2] &&
+                      a.g.translucent_absorption[0] == a.g.translucent_absorption[1] && a.g.translucent_absorption[0] == a.g.translucent_absorption[2];
     auto bssrdf = [&](float radius) -> f3 {
         if (MODE != 0) {
             f3 tv = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, radius / scale)
                               : sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, radius / scale);
             return (a.fudge * tv) / z;
         }
+        if (grey) { float v = dipole_eval(cr, radius); return mk3(v, v, v); }
         return mk3(dipole_eval(cr, radius), dipole_eval(cg, radius), dipole_eval(cb, radius));
     };
     f3 E = mk3(0.0f, 0.0f, 0.0f);

@@ -145,3 +145,14 @@ def test_hierarchical_gather_against_the_exact_sum():
     print("hierarchical gather, limit 0.5 sr: %.1fx fewer terms, image RMSE %.2e" % (terms["exact"] / terms["approx"], rmse))
     assert rmse < 1e-2
     assert terms["approx"] * 2 < terms["exact"]
+
+
+def test_dipole_with_per_channel_coefficients(oracle_mod):
+    """the shipped defaults share one (sigma_s, sigma_a) across r, g, b (main.cpp:420-422), which the gather kernel
+    evaluates once; distinct coefficients take the per-channel path"""
+    s = scenes.cornell_bunny(96, 54, spp=1, bounces=2, tabulated=False, sample_radius=0.05)
+    s.globals.translucent_scattering[:] = (15.0, 9.0, 4.0)
+    s.globals.translucent_absorption[:] = (0.1, 0.3, 0.9)
+    _check_translucent(s, oracle_mod, frames=2)
+    s.gather_mode = (True, 0.3)
+    _check_translucent(s, oracle_mod, frames=1)
