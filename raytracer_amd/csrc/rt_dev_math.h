@@ -232,6 +232,41 @@ RT_DEV float dipole_eval(const DipoleConst& c, float radius) {
     return r > 0.0f ? r : 0.0f;
 }
 
+// Hardware approximations (1-2 ulp), used only where the result is covered by a tolerance and never decides a hit id
+// or an RNG draw: the conservative box test and the BSSRDF gather (radiance, 1e-4).
+RT_DEV float fast_rcp(float x) {
+#if defined(__HIPCC__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+RT_DEV float fast_sqrt(float x) {
+#if defined(__HIPCC__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+RT_DEV float fast_exp(float x) {
+#if defined(__HIPCC__)
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+#else
+    return expf(x);
+#endif
+}
+// dipole_eval with hardware rcp / exp2: same formula, a few ulp from the IEEE evaluation
+RT_DEV float dipole_eval_fast(const DipoleConst& c, float radius) {
+    float d_real = radius + c.z_real, d_virtual = radius + c.z_virtual;
+    float ir = fast_rcp(d_real), iv = fast_rcp(d_virtual);
+    float c_real = c.z_real * (c.sigma_tr + ir);
+    float c_virtual = c.z_virtual * (c.sigma_tr + iv);
+    float m_real = c_real * fast_exp(-c.sigma_tr * d_real) * (ir * ir);
+    float m_virtual = c_virtual * fast_exp(-c.sigma_tr * d_virtual) * (iv * iv);
+    float r = c.scale * (m_real + m_virtual);
+    return r > 0.0f ? r : 0.0f;
+}
+
 RT_DEV unsigned char to_unorm8(float x) {             // S9
     if (!(x > 0.0f)) return 0;
     if (x > 1.0f) x = 1.0f;

@@ -65,14 +65,6 @@ struct BoxRay {
     float pad;             // absolute padding in t
 };
 
-RT_DEV float fast_rcp(float x) {
-#if defined(__HIPCC__)
-    return __builtin_amdgcn_rcpf(x);
-#else
-    return 1.0f / x;
-#endif
-}
-
 // Slab distances are (plane - origin) * (1/d): the subtraction is exact to half an ulp of its result, so a relative
 // pad covers the rounding of the box test itself, whatever the size of 1/d.  The absolute pad covers the rounding of
 // the *triangle* test, whose t is a quotient of sums of terms of size (extent + |o|) / max|d| (S4): two hits closer
