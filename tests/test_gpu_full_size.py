@@ -54,3 +54,4 @@ def test_1080p_determinism_and_tile_split():
         assert np.array_equal(ctx[0].read_render_target(), ctx[1].read_render_target())
     finally:
         for rt in ctx: rt.close()
+
