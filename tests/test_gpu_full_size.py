@@ -55,3 +55,10 @@ def test_1080p_determinism_and_tile_split():
     finally:
         for rt in ctx: rt.close()
 
+
+def test_c5_all_52743_instances_low_resolution(oracle_mod):
+    """C5's scene at its full instance count (50 M instanced triangles, the 105 k-node TLAS); the resolution is reduced
+    because the oracle walks this TLAS at ~20 k rays/s (tools/c5_full_parity.py is the same check at any size)"""
+    scene = scenes.bunny_field(160, 90, spp=1, bounces=4)
+    assert scene.triangle_count() > 49000000
+    assert _full_parity(scene, oracle_mod, frames=1) > 160 * 90
