@@ -195,6 +195,8 @@ struct Counters { u64 nodes, tris, insts, rays; };
 struct Scene {
     std::vector<Blas> blas;
     std::vector<Instance> instances;
+    std::vector<BvhNode> tlas;          // oracle-side top-level BVH over the instances' world boxes (median splits)
+    std::vector<int> tlas_instances;    // leaf order
     std::vector<TranslucentMesh> translucent_meshes;
     std::vector<float> translucent_mean_area;      // g_translucent_properties (by translucent_id)
     std::vector<float> properties_by_slot;         // uploaded instanced layout (raytracing.cpp:599-600)
@@ -483,19 +485,64 @@ void intersect_blas(const Scene& s, int inst_index, V3 o, V3 d, float tmin, floa
     }
 }
 
+// top-level BVH over instance boxes: median split of the box centres along the widest axis, one instance per leaf.
+// The answer does not depend on it (S5: ties go to the lowest instance / primitive whatever the visiting order).
+int build_tlas_rec(Scene& s, int first, int count) {
+    int id = (int) s.tlas.size();
+    s.tlas.push_back(BvhNode());
+    BvhNode n;
+    for (int k = 0; k < 3; k++) { n.lo[k] = F_INF; n.hi[k] = -F_INF; }
+    float clo[3] = { F_INF, F_INF, F_INF }, chi[3] = { -F_INF, -F_INF, -F_INF };
+    for (int i = first; i < first + count; i++) {
+        const Instance& in = s.instances[s.tlas_instances[i]];
+        for (int k = 0; k < 3; k++) {
+            n.lo[k] = std::min(n.lo[k], in.wlo[k]); n.hi[k] = std::max(n.hi[k], in.whi[k]);
+            float c = 0.5f * (in.wlo[k] + in.whi[k]);
+            clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c);
+        }
+    }
+    n.first = first; n.count = count; n.left = -1; n.right = -1;
+    if (count > 1) {
+        int axis = 0;
+        if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+        if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+        int mid = first + count / 2;
+        std::nth_element(s.tlas_instances.begin() + first, s.tlas_instances.begin() + mid, s.tlas_instances.begin() + first + count,
+                         [&](int a, int b) {
+                             float ca = s.instances[a].wlo[axis] + s.instances[a].whi[axis], cb = s.instances[b].wlo[axis] + s.instances[b].whi[axis];
+                             return ca < cb || (ca == cb && a < b);
+                         });
+        n.left = build_tlas_rec(s, first, mid - first);
+        n.right = build_tlas_rec(s, mid, first + count - mid);
+    }
+    s.tlas[id] = n;
+    return id;
+}
+void build_tlas_bvh(Scene& s) {
+    s.tlas.clear();
+    s.tlas_instances.resize(s.instances.size());
+    for (size_t i = 0; i < s.instances.size(); i++) s.tlas_instances[i] = (int) i;
+    if (!s.instances.empty()) build_tlas_rec(s, 0, (int) s.instances.size());
+}
+
 // TraceRay (raytracing.hlsl:108-112): closest hit over all instances, RAY_FLAG_CULL_BACK_FACING_TRIANGLES
 Hit trace_ray(const Scene& s, V3 o, V3 d, float tmin, float tmax, Counters& cnt) {
     Hit best; best.inst = -1; best.geom = -1; best.prim = -1; best.prim_global = 0; best.t = F_INF; best.u = best.v = 0;
     cnt.rays++;
-    V3 inv_d = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    for (int i = 0; i < (int) s.instances.size(); i++) {
-        if (!s.brute_force) {
-            const Instance& in = s.instances[i];
-            float lo[3] = { in.wlo.x, in.wlo.y, in.wlo.z }, hi[3] = { in.whi.x, in.whi.y, in.whi.z };
+    if (s.brute_force) {
+        for (int i = 0; i < (int) s.instances.size(); i++) intersect_blas(s, i, o, d, tmin, tmax, best, cnt);
+    } else if (!s.tlas.empty()) {
+        V3 inv_d = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        int stack[128]; int sp = 0; stack[sp++] = 0;
+        while (sp) {
+            const BvhNode& n = s.tlas[stack[--sp]];
             float tcap = best.t < tmax ? best.t : tmax;
-            if (!box_hit(lo, hi, o, inv_d, tmin, tcap)) continue;
+            if (!box_hit(n.lo, n.hi, o, inv_d, tmin, tcap)) continue;
+            if (n.left < 0) { intersect_blas(s, s.tlas_instances[n.first], o, d, tmin, tmax, best, cnt); continue; }
+            cnt.nodes++; // an expanded top-level node, counted like the bottom-level ones (N_node)
+            if (sp + 2 > 128) abort();
+            stack[sp++] = n.right; stack[sp++] = n.left;
         }
-        intersect_blas(s, i, o, d, tmin, tmax, best, cnt);
     }
     if (best.inst >= 0) {
         const Blas& b = s.blas[s.instances[best.inst].blas];
@@ -1185,6 +1232,7 @@ int orc_build_tlas(orc_scene* o, const RtInstance* instances, int n) {
         }
         s.instances.push_back(in);
     }
+    build_tlas_bvh(s);
     return 0;
 }
 
