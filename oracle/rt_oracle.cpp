@@ -435,6 +435,19 @@ inline bool box_hit(const float* lo, const float* hi, V3 o, V3 inv_d, float tmin
     return t0 <= t1;
 }
 
+// entry distance of the padded slab test, or +inf for a miss
+inline float box_entry(const float* lo, const float* hi, V3 o, V3 inv_d, float tmin, float tmax) {
+    float t0 = tmin, t1 = tmax;
+    for (int a = 0; a < 3; a++) {
+        float ta = (lo[a] - o[a]) * inv_d[a], tb = (hi[a] - o[a]) * inv_d[a];
+        float tn = fminf(ta, tb), tf = fmaxf(ta, tb);
+        tn = tn - fabsf(tn) * 4e-7f - 1e-30f; tf = tf + fabsf(tf) * 4e-7f + 1e-30f;
+        t0 = fmaxf(t0, tn); t1 = fminf(t1, tf);
+    }
+    return t0 <= t1 ? t0 : F_INF;
+}
+struct StackEntry { int node; float entry; };
+
 void intersect_blas(const Scene& s, int inst_index, V3 o, V3 d, float tmin, float tmax, Hit& best, Counters& cnt) {
     const Instance& inst = s.instances[inst_index];
     const Blas& b = s.blas[inst.blas];
@@ -458,13 +471,17 @@ void intersect_blas(const Scene& s, int inst_index, V3 o, V3 d, float tmin, floa
         return;
     }
     V3 inv_d = v3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
-    int stack[128]; int sp = 0; stack[sp++] = 0;
+    StackEntry stack[128]; int sp = 0;
+    {
+        const BvhNode& root = b.nodes[0];
+        float e = box_entry(root.lo, root.hi, oo, inv_d, tmin, best.t < tmax ? best.t : tmax);
+        if (e < F_INF) { stack[sp].node = 0; stack[sp].entry = e; sp++; }
+    }
     while (sp) {
-        const BvhNode& n = b.nodes[stack[--sp]];
+        StackEntry se = stack[--sp];
         float tcap = best.t < tmax ? best.t : tmax;
-        if (!box_hit(n.lo, n.hi, oo, inv_d, tmin, tcap)) continue;
-        // one expanded inner node == one 64-byte two-child node fetched in the GPU layout (N_node)
-        if (n.left >= 0) cnt.nodes++;
+        if (se.entry > tcap) continue; // a closer hit was found since this node was pushed
+        const BvhNode& n = b.nodes[se.node];
         if (n.left < 0) {
             for (int k = n.first; k < n.first + n.count; k++) {
                 u32 i = b.bvh_tris[k];
@@ -479,8 +496,16 @@ void intersect_blas(const Scene& s, int inst_index, V3 o, V3 d, float tmin, floa
                 best.t = t; best.u = u; best.v = v; best.inst = inst_index; best.prim_global = i;
             }
         } else {
+            // one expanded inner node == one 64-byte two-child node fetched in the GPU layout (N_node):
+            // both child boxes are tested here and the nearer child is visited first
+            cnt.nodes++;
+            const BvhNode& l = b.nodes[n.left]; const BvhNode& r = b.nodes[n.right];
+            float el = box_entry(l.lo, l.hi, oo, inv_d, tmin, tcap), er = box_entry(r.lo, r.hi, oo, inv_d, tmin, tcap);
             if (sp + 2 > 128) abort();
-            stack[sp++] = n.right; stack[sp++] = n.left;
+            StackEntry a = { n.left, el }, c = { n.right, er };
+            if (er < el) { StackEntry t = a; a = c; c = t; } // a = nearer
+            if (c.entry < F_INF) stack[sp++] = c;
+            if (a.entry < F_INF) stack[sp++] = a;
         }
     }
 }
@@ -533,15 +558,25 @@ Hit trace_ray(const Scene& s, V3 o, V3 d, float tmin, float tmax, Counters& cnt)
         for (int i = 0; i < (int) s.instances.size(); i++) intersect_blas(s, i, o, d, tmin, tmax, best, cnt);
     } else if (!s.tlas.empty()) {
         V3 inv_d = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        int stack[128]; int sp = 0; stack[sp++] = 0;
+        StackEntry stack[128]; int sp = 0;
+        {
+            float e = box_entry(s.tlas[0].lo, s.tlas[0].hi, o, inv_d, tmin, tmax);
+            if (e < F_INF) { stack[sp].node = 0; stack[sp].entry = e; sp++; }
+        }
         while (sp) {
-            const BvhNode& n = s.tlas[stack[--sp]];
+            StackEntry se = stack[--sp];
             float tcap = best.t < tmax ? best.t : tmax;
-            if (!box_hit(n.lo, n.hi, o, inv_d, tmin, tcap)) continue;
+            if (se.entry > tcap) continue;
+            const BvhNode& n = s.tlas[se.node];
             if (n.left < 0) { intersect_blas(s, s.tlas_instances[n.first], o, d, tmin, tmax, best, cnt); continue; }
             cnt.nodes++; // an expanded top-level node, counted like the bottom-level ones (N_node)
+            const BvhNode& l = s.tlas[n.left]; const BvhNode& r = s.tlas[n.right];
+            float el = box_entry(l.lo, l.hi, o, inv_d, tmin, tcap), er = box_entry(r.lo, r.hi, o, inv_d, tmin, tcap);
             if (sp + 2 > 128) abort();
-            stack[sp++] = n.right; stack[sp++] = n.left;
+            StackEntry a = { n.left, el }, c = { n.right, er };
+            if (er < el) { StackEntry t = a; a = c; c = t; }
+            if (c.entry < F_INF) stack[sp++] = c;
+            if (a.entry < F_INF) stack[sp++] = a;
         }
     }
     if (best.inst >= 0) {
