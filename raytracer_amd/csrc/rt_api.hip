@@ -54,7 +54,7 @@ template <typename T> void dev_free(T*& p) { if (p) { (void) hipFree(p); p = nul
 struct rt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    LbvhWorkspace lbvh; PlocWorkspace ploc; int bvh_builder = 1; float sah_tri = 1.3f; // RT_BVH_BUILDER: 0 LBVH, 1 PLOC; RT_SAH_TRI
+    LbvhWorkspace lbvh; PlocWorkspace ploc; SahWorkspace sah; int bvh_builder = 2; float sah_tri = 1.3f; // RT_BVH_BUILDER: 0 LBVH, 1 PLOC, 2 binned SAH (default), 3 SAH for BLAS + PLOC for the TLAS; RT_SAH_TRI
     bool exact_instance_boxes = true; // RT_EXACT_INSTANCE_BOXES=0: TLAS boxes from the corners of the BLAS box (tuning aid)
     std::vector<Blas> blas;
     std::vector<TranslucentMesh> translucent_meshes;
@@ -332,7 +332,7 @@ void rt_destroy(rt_ctx* c) {
     dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
     dev_free(c->d_accumulator); dev_free(c->d_render_target); dev_free(c->d_capture); dev_free(c->d_arena);
     dev_free(c->d_seg_count); dev_free(c->d_stats); dev_free(c->d_table[0]); dev_free(c->d_table[1]);
-    lbvh_workspace_free(c->lbvh); ploc_workspace_free(c->ploc);
+    lbvh_workspace_free(c->lbvh); ploc_workspace_free(c->ploc); sah_workspace_free(c->sah);
     if (c->own_stream) (void) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -450,7 +450,7 @@ int rt_build_blas(rt_ctx* c, const RtGeometry* geometries, int n, rt_blas* out) 
     int rc = lbvh_workspace_reserve(c->lbvh, b.n_tris); if (rc) return rc;
     RT_HIP(hipEventRecord(e0, c->stream));
     rc = lbvh_triangle_boxes(c->stream, c->lbvh, b.d_verts, b.d_indices, b.n_tris); if (rc) return rc;
-    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, c->bvh_builder, c->sah_tri, b.n_tris, RT_LEAF_MAX_TRIS, false, b.d_nodes, b.d_perm); if (rc) return rc;
+    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, b.n_tris, RT_LEAF_MAX_TRIS, false, b.d_nodes, b.d_perm); if (rc) return rc;
     rc = lbvh_write_trirecs(c->stream, b.d_perm, b.d_verts, b.d_indices, b.d_tri_geometry, b.d_geoms, b.n_tris, b.d_tris); if (rc) return rc;
     RT_HIP(hipEventRecord(e1, c->stream));
     BvhNode root;
@@ -516,7 +516,7 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
     RT_HIP(hipEventRecord(e0, c->stream));
     const bool exact_boxes = c->exact_instance_boxes && vertex_work <= (4ull << 30);
     rc = lbvh_instance_boxes(c->stream, c->lbvh, c->d_inst_shade, c->d_inst_rec, (u32) n, exact_boxes); if (rc) return rc;
-    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, c->bvh_builder, c->sah_tri, (u32) n, 1, true, c->d_tlas_nodes, c->d_tlas_perm); if (rc) return rc;
+    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, (u32) n, 1, true, c->d_tlas_nodes, c->d_tlas_perm); if (rc) return rc;
     RT_HIP(hipEventRecord(e1, c->stream));
     BvhNode root;
     RT_HIP(hipMemcpyAsync(&root, c->d_tlas_nodes, sizeof root, hipMemcpyDeviceToHost, c->stream));

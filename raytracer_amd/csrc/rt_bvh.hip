@@ -267,7 +267,7 @@ int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const InstShade* shade,
     return RT_OK;
 }
 
-int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, BvhNode* nodes_out, u32* perm_out) {
+int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace* sw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, BvhNode* nodes_out, u32* perm_out) {
     if (n == 0 || n > w.capacity) { set_error("lbvh_build: bad primitive count %u", n); return RT_ERR_INVALID; }
     hipLaunchKernelGGL(k_scene_box, dim3(1), dim3(1024), 0, s, w.boxes, n, w.scene_box);
     hipLaunchKernelGGL(k_morton, grid_for(n), dim3(BT), 0, s, w.boxes, w.scene_box, n, w.keys, w.vals);
@@ -279,7 +279,8 @@ int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, int builder, 
         RT_HIP(hipGetLastError());
         return RT_OK;
     }
-    if (builder == 1 && pw) return ploc_build(s, w, *pw, n, leaf_max, sah_tri, tlas, nodes_out, perm_out);
+    if ((builder == 2 || (builder == 3 && !tlas)) && sw && n <= SAH_BUILD_MAX) return sah_build(s, w, *sw, n, leaf_max, sah_tri, tlas, nodes_out, perm_out);
+    if (builder >= 1 && pw) return ploc_build(s, w, *pw, n, leaf_max, sah_tri, tlas, nodes_out, perm_out);
     RT_HIP(hipMemsetAsync(w.flags, 0, (size_t) n * 4, s));
     RT_HIP(hipMemsetAsync(w.depth, 0, (size_t) n * 4, s));
     hipLaunchKernelGGL(k_hierarchy, grid_for(n - 1), dim3(BT), 0, s, w.keys, (int) n, w.build_nodes, w.leaf_parent);

@@ -61,15 +61,25 @@ int ploc_workspace_reserve(PlocWorkspace& w, u32 n);
 void ploc_workspace_free(PlocWorkspace& w);
 int ploc_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace& pw, u32 n, int leaf_max, float sah_tri, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
 
+struct SahWorkspace { // rt_sah.hip (builder 2: top-down binned SAH)
+    void* bins = nullptr; void* tasks[2] = { nullptr, nullptr }; void* decisions = nullptr; u32* counters = nullptr;
+    u32 capacity = 0;
+};
+int sah_workspace_reserve(SahWorkspace& w, u32 n);
+void sah_workspace_free(SahWorkspace& w);
+int sah_build(hipStream_t s, LbvhWorkspace& w, SahWorkspace& sw, u32 n, int leaf_max, float sah_tri, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
+
 // boxes for the n triangles of a BLAS -> w.boxes
 int lbvh_triangle_boxes(hipStream_t s, LbvhWorkspace& w, const RtVertex* verts, const uint16_t* indices, u32 n_tris);
 // world boxes of n instances (8 corners of each BLAS root box through object_to_world, padded) -> w.boxes
 // exact: boxes from every vertex of the instance's BLAS (tighter); otherwise from the corners of its object-space box
 int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const rtd::InstShade* shade, const rtd::InstRec* insts, u32 n, bool exact);
 // builds the hierarchy over w.boxes[0..n); nodes_out has max(1, n-1) entries; perm_out[n] = sorted -> original.
-// builder: 0 = Karras LBVH hierarchy, 1 = PLOC agglomerative clustering (pw required)
+// builder: 0 = Karras LBVH hierarchy, 1 = PLOC agglomerative clustering (pw required), 2 = top-down binned SAH for
+// up to SAH_BUILD_MAX primitives (sw required; larger inputs fall back to PLOC)
 // sah_tri: cost of one triangle test relative to one two-child node step in the surface-area heuristic
-int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
+static constexpr u32 SAH_BUILD_MAX = 1u << 18;
+int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace* sw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
 // TriRec array in leaf order
 int lbvh_write_trirecs(hipStream_t s, const u32* perm, const RtVertex* verts, const uint16_t* indices,
                        const u32* tri_geometry, const rtd::GeomRec* geoms, u32 n_tris, rtd::TriRec* out);

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from raytracer_amd import api, scenes, distributed, _abi
 
-variants = sys.argv[1:] or ["0", "1"]
+variants = sys.argv[1:] or ["1", "2"]
 workloads = {"c2": lambda: scenes.bunny(1920, 1080, spp=1, bounces=1),
              "c3": lambda: scenes.cornell(1920, 1080, spp=4, bounces=4)}
 rounds, steps = 5, 6

@@ -12,7 +12,7 @@ def soup(n, seed):
     v = np.zeros(n * 3, dtype=_abi.VERTEX_DTYPE); v["position"] = t.reshape(-1, 3); v["normal"][:, 2] = 1
     return v, np.arange(n * 3, dtype=np.uint16)
 
-for builder in ("1", "0"):
+for builder in ("2", "1", "0"):
     os.environ["RT_BVH_BUILDER"] = builder
     rt = api.Raytracer(0)
     rt.update_resolution(64, 64)
