@@ -280,6 +280,22 @@ int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace*
         return RT_OK;
     }
     if ((builder == 2 || (builder == 3 && !tlas)) && sw && n <= SAH_BUILD_MAX) return sah_build(s, w, *sw, n, leaf_max, sah_tri, tlas, nodes_out, perm_out);
+    if (builder == 4 && sw && pw && n <= SAH_BUILD_MAX) {
+        // neither build wins everywhere (SAH: large meshes and instance fields; PLOC: a handful of big triangles), and
+        // both are cheap next to the frames traced through them: build both, keep the cheaper tree
+        rc = ploc_build(s, w, *pw, n, leaf_max, sah_tri, tlas, nodes_out, perm_out); if (rc != RT_OK) return rc;
+        rc = sah_workspace_reserve(*sw, n); if (rc != RT_OK) return rc;
+        rc = sah_build(s, w, *sw, n, leaf_max, sah_tri, tlas, sw->alt_nodes, sw->alt_perm); if (rc != RT_OK) return rc;
+        float cost_ploc = 0.0f, cost_sah = 0.0f;
+        RT_HIP(hipMemcpyAsync(&cost_ploc, w.cost + (n - 2), 4, hipMemcpyDeviceToHost, s)); // the root is PLOC's last node
+        RT_HIP(hipMemcpyAsync(&cost_sah, sw->counters + 3, 4, hipMemcpyDeviceToHost, s));
+        RT_HIP(hipStreamSynchronize(s));
+        if (cost_sah < cost_ploc) {
+            RT_HIP(hipMemcpyAsync(nodes_out, sw->alt_nodes, sizeof(BvhNode) * (size_t) (n - 1), hipMemcpyDeviceToDevice, s));
+            RT_HIP(hipMemcpyAsync(perm_out, sw->alt_perm, 4 * (size_t) n, hipMemcpyDeviceToDevice, s));
+        }
+        return RT_OK;
+    }
     if (builder >= 1 && pw) return ploc_build(s, w, *pw, n, leaf_max, sah_tri, tlas, nodes_out, perm_out);
     RT_HIP(hipMemsetAsync(w.flags, 0, (size_t) n * 4, s));
     RT_HIP(hipMemsetAsync(w.depth, 0, (size_t) n * 4, s));

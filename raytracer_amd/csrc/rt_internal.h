@@ -62,7 +62,9 @@ void ploc_workspace_free(PlocWorkspace& w);
 int ploc_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace& pw, u32 n, int leaf_max, float sah_tri, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
 
 struct SahWorkspace { // rt_sah.hip (builder 2: top-down binned SAH)
-    void* bins = nullptr; void* tasks[2] = { nullptr, nullptr }; void* decisions = nullptr; u32* counters = nullptr;
+    void* bins = nullptr; void* tasks[2] = { nullptr, nullptr }; void* decisions = nullptr;
+    u32* counters = nullptr;                                   // tasks of the level, inner nodes, depth, tree cost (float)
+    rtd::BvhNode* alt_nodes = nullptr; u32* alt_perm = nullptr; // second tree when two builders compete (builder 4)
     u32 capacity = 0;
 };
 int sah_workspace_reserve(SahWorkspace& w, u32 n);
@@ -76,7 +78,8 @@ int lbvh_triangle_boxes(hipStream_t s, LbvhWorkspace& w, const RtVertex* verts, 
 int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const rtd::InstShade* shade, const rtd::InstRec* insts, u32 n, bool exact);
 // builds the hierarchy over w.boxes[0..n); nodes_out has max(1, n-1) entries; perm_out[n] = sorted -> original.
 // builder: 0 = Karras LBVH hierarchy, 1 = PLOC agglomerative clustering (pw required), 2 = top-down binned SAH for
-// up to SAH_BUILD_MAX primitives (sw required; larger inputs fall back to PLOC)
+// up to SAH_BUILD_MAX primitives (sw required; larger inputs fall back to PLOC), 3 = SAH for bottom-level trees and
+// PLOC for the top level, 4 = both PLOC and SAH, keeping the tree with the lower surface-area cost
 // sah_tri: cost of one triangle test relative to one two-child node step in the surface-area heuristic
 static constexpr u32 SAH_BUILD_MAX = 1u << 18;
 int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace* sw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);

@@ -235,6 +235,30 @@ __global__ void k_sah_finish(const Aabb* __restrict__ scene, const u32* __restri
     }
 }
 
+// surface-area cost of the finished tree, the quantity the PLOC build keeps in its cost array: sum over inner nodes of
+// their half area + sah_tri * (primitives * half area) over leaves.  One workgroup, fixed summation order.
+__global__ __launch_bounds__(1024) void k_sah_cost(const BvhNode* __restrict__ nodes, const u32* __restrict__ counters, float sah_tri, int tlas,
+                                                   float* __restrict__ out) {
+    __shared__ float s_sum[1024];
+    const u32 n_nodes = counters[1];
+    float sum = 0.0f;
+    for (u32 i = threadIdx.x; i < n_nodes; i += 1024u) {
+        const BvhNode nd = nodes[i];
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(nd.lo0[k], nd.lo1[k]); hi[k] = fmaxf(nd.hi0[k], nd.hi1[k]); }
+        sum += sah_half_area(lo, hi);
+        if (nd.c0 < 0) sum += sah_tri * (float) (tlas ? 1u : ((u32) (~nd.c0) & 7u) + 1u) * sah_half_area(nd.lo0, nd.hi0);
+        if (nd.c1 < 0) sum += sah_tri * (float) (tlas ? 1u : ((u32) (~nd.c1) & 7u) + 1u) * sah_half_area(nd.lo1, nd.hi1);
+    }
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (u32 off = 512; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = s_sum[0];
+}
+
 int sah_workspace_reserve(SahWorkspace& w, u32 n) {
     if (n <= w.capacity) return RT_OK;
     sah_workspace_free(w);
@@ -245,11 +269,13 @@ int sah_workspace_reserve(SahWorkspace& w, u32 n) {
     RT_HIP(hipMalloc(&w.tasks[1], sizeof(SahTask) * (size_t) cap));
     RT_HIP(hipMalloc(&w.decisions, sizeof(SahDecision) * (size_t) cap));
     RT_HIP(hipMalloc(&w.counters, 4 * sizeof(u32)));
+    RT_HIP(hipMalloc(&w.alt_nodes, sizeof(BvhNode) * (size_t) cap));
+    RT_HIP(hipMalloc(&w.alt_perm, 4 * (size_t) cap));
     w.capacity = cap;
     return RT_OK;
 }
 void sah_workspace_free(SahWorkspace& w) {
-    void* ptrs[] = { w.bins, w.tasks[0], w.tasks[1], w.decisions, w.counters };
+    void* ptrs[] = { w.bins, w.tasks[0], w.tasks[1], w.decisions, w.counters, w.alt_nodes, w.alt_perm };
     for (void* p : ptrs) if (p) (void) hipFree(p);
     w = SahWorkspace();
 }
@@ -280,6 +306,8 @@ int sah_build(hipStream_t s, LbvhWorkspace& w, SahWorkspace& sw, u32 n, int leaf
         cur ^= 1;
     }
     if (n_tasks != 0) { set_error("sah_build: the tree did not close after 96 levels"); return RT_ERR_LIMIT; }
+    // cost first: k_sah_finish rewrites the leaf links of a top-level tree (counters[3] holds the cost as a float)
+    hipLaunchKernelGGL(k_sah_cost, dim3(1), dim3(1024), 0, s, (const BvhNode*) nodes_out, (const u32*) sw.counters, sah_tri, tlas ? 1 : 0, (float*) (sw.counters + 3));
     hipLaunchKernelGGL(k_sah_finish, grid_for(n), dim3(BT), 0, s, w.scene_box, sw.counters, idx[cur], tlas ? 1 : 0, nodes_out);
     RT_HIP(hipMemcpyAsync(perm_out, idx[cur], (size_t) n * 4, hipMemcpyDeviceToDevice, s));
     RT_HIP(hipGetLastError());

@@ -102,10 +102,10 @@ def test_many_instances_of_tiny_blas(oracle_mod):
     _check_scene(s, oracle_mod, frames=1, brute_force=True)
 
 
-@pytest.mark.parametrize("builder", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("builder", ["0", "1", "2", "3", "4"])
 def test_every_bvh_builder_gives_the_same_hits(oracle_mod, monkeypatch, builder):
-    """the closest hit does not depend on the tree (S5): Karras LBVH (0), PLOC (1), binned SAH (2, default) and the
-    SAH-BLAS / PLOC-TLAS mix (3) against brute force"""
+    """the closest hit does not depend on the tree (S5): Karras LBVH (0), PLOC (1), binned SAH (2), the
+    SAH-BLAS / PLOC-TLAS mix (3), the cheaper of PLOC and SAH (4, default) against brute force"""
     monkeypatch.setenv("RT_BVH_BUILDER", builder)       # read at rt_create
     _check_scene(scenes.bunny(96, 54, spp=1, bounces=3), oracle_mod)
     _check_scene(scenes.bunny_field(96, 54, spp=1, bounces=2, grid=8, count=40), oracle_mod, brute_force=False)
