@@ -113,7 +113,7 @@ RT_DEV Quad ldq(const RT_GLOBAL void* base, int quad_index) { return ((const RT_
 // The per-ray state is a struct so that kernels can set a ray up (trace_begin) and run it (trace_run) separately.
 struct TraceState {
     HitOut best;
-    bool have_hit, bottom, need_pop;
+    bool have_hit, bottom;
     int cur_inst;  // instance being traversed (bottom level)
     int cur;       // node link in hand, RT_TRAVERSAL_DONE when the ray is finished
     const RT_GLOBAL BvhNode* nodes;
@@ -146,7 +146,7 @@ RT_DEV void trace_bottom_level(const SceneView& sc, f3 o, f3 d, TraceState& S) {
 
 RT_DEV void trace_begin(const SceneView& sc, f3 o, f3 d, float tmax, TraceState& S) {
     S.best.t = tmax; S.best.u = 0.0f; S.best.v = 0.0f; S.best.inst = -1; S.best.tri = -1; S.best.prim_global = 0;
-    S.have_hit = false; S.need_pop = false; S.cur_inst = -1; S.tris = nullptr;
+    S.have_hit = false; S.cur_inst = -1; S.tris = nullptr;
     S.rp.o = o; S.rp.kx = 0; S.rp.ky = 1; S.rp.kz = 2; S.rp.sx = S.rp.sy = S.rp.sz = 0.0f;
     trace_top_level(sc, o, d, S);
     // a NaN in the ray makes every triangle test fail (S4 compares with NaN are false): the answer is a miss, and
@@ -157,43 +157,44 @@ RT_DEV void trace_begin(const SceneView& sc, f3 o, f3 d, float tmax, TraceState&
 }
 
 // Runs the ray to the end; S.best is then final (t = +inf for a miss).
-// `Stack` provides push(int) / pop() / empty(); COUNT enables the traversal counters.
+// `Stack` provides reset() / top() / put(v, really) / push(v) / pop() and the stack pointer `sp`; COUNT enables the
+// traversal counters.  The bottom stack entry is a RT_TRAVERSAL_DONE sentinel, so a pop never has to ask whether the
+// stack is empty, and "back to the top level" (RT_STACK_MARKER) and "finished" are handled like leaves.
+//
+// The node step is straight-line code: the entry a pop would return is read together with the node (it is needed by
+// the lanes whose boxes both miss), the far child is stored above the top of the stack whether or not it is kept, and
+// the stack pointer moves by (both hit) - (none hit).  A wave pays every path that any of its lanes takes, so the
+// branchy form (pop / descend / push as separate exec-masked regions, ~60 scalar instructions per step) cost the sum
+// of all of them on most steps.
 template <class Stack, bool COUNT>
 RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, Stack& st, TraceState& S, TraverseCounters& cnt) {
-    while (S.cur != RT_TRAVERSAL_DONE) {
+    st.reset();
+    for (;;) {
         // ---- inner nodes ---------------------------------------------------------------------------------------
-        for (;;) {
-            if (S.need_pop) {
-                S.need_pop = false;
-                if (st.empty()) S.cur = RT_TRAVERSAL_DONE;
-                else {
-                    S.cur = st.pop();
-                    if (S.cur == RT_STACK_MARKER) { // back to the top level
-                        trace_top_level(sc, o, d, S);
-                        if (st.empty()) S.cur = RT_TRAVERSAL_DONE; else S.cur = st.pop();
-                    }
-                }
-            }
-            if (S.cur < 0) break;
+        while (S.cur >= 0) {
             const RT_GLOBAL BvhNode* n = S.nodes + S.cur;
             Quad q0 = ldq(n, 0), q1 = ldq(n, 1), q2 = ldq(n, 2), q3 = ldq(n, 3);
+            const int top = st.top();
             if (COUNT) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; }
             float lo0[3] = { q0.x, q0.y, q0.z }, hi0[3] = { q0.w, q1.x, q1.y };
             float lo1[3] = { q1.z, q1.w, q2.x }, hi1[3] = { q2.y, q2.z, q2.w };
             float e0, e1;
-            bool h0 = box_test(S.br, lo0, hi0, tmin, S.best.t, e0);
-            bool h1 = box_test(S.br, lo1, hi1, tmin, S.best.t, e1);
-            int c0 = (int) as_u32(q3.x), c1 = (int) as_u32(q3.y);
-            if (h0 && h1) {
-                bool first0 = e0 <= e1;
-                st.push(first0 ? c1 : c0);
-                S.cur = first0 ? c0 : c1;
-            } else if (h0) S.cur = c0;
-            else if (h1) S.cur = c1;
-            else S.need_pop = true;
+            const bool h0 = box_test(S.br, lo0, hi0, tmin, S.best.t, e0);
+            const bool h1 = box_test(S.br, lo1, hi1, tmin, S.best.t, e1);
+            const int c0 = (int) as_u32(q3.x), c1 = (int) as_u32(q3.y);
+            const bool both = h0 & h1, any = h0 | h1, first0 = e0 <= e1;
+            st.put(first0 ? c1 : c0, both);       // the far child, kept only when both boxes are hit
+            int next = h0 ? c0 : c1;              // the only child hit ...
+            next = both ? (first0 ? c0 : c1) : next; // ... or the nearer of the two
+            S.cur = any ? next : top;
+            st.sp += (both ? 1 : 0) - (any ? 0 : 1);
         }
         if (S.cur == RT_TRAVERSAL_DONE) break;
-        if (!S.bottom) {
+        if (S.cur == RT_STACK_MARKER) {
+            // ---- the instance is finished: back to the top level ---------------------------------------------------
+            trace_top_level(sc, o, d, S);
+            S.cur = st.pop();
+        } else if (!S.bottom) {
             // ---- TLAS leaf: enter the instance ---------------------------------------------------------------------
             S.cur_inst = ~S.cur;
             if (COUNT) { cnt.insts++; if (first_active_lane()) cnt.inst_trips++; }
@@ -220,7 +221,7 @@ RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, S
                     S.best.prim_global = prim_global; S.have_hit = true;
                 }
             }
-            S.need_pop = true;
+            S.cur = st.pop();
         }
     }
     if (!S.have_hit) S.best.t = inf_f32();

@@ -20,31 +20,34 @@ namespace rti {
 using namespace rtd;
 
 static constexpr int TRAVERSE_WAVE   = 64;
-static constexpr int LDS_STACK_DEPTH = 32;  // entries per lane kept in LDS (8 KB per wave: 20 waves/CU = the VGPR limit)
-static constexpr int OVF_STACK_DEPTH = 32;  // global spill; the host checks tlas_depth + 1 + blas_depth <= 64
+static constexpr int LDS_STACK_DEPTH = 31;  // entries per lane kept in LDS; row 31 of the 8 KB per wave (20 waves/CU = the VGPR limit) is a dump row
+static constexpr int OVF_STACK_DEPTH = 32;  // global spill; 63 entries with the sentinel; the host checks tlas_depth + 1 + blas_depth <= 64
 static constexpr int BT = 256;
 static constexpr int SEG = 1024;            // rays per queue segment = threads per raygen / shade workgroup
 
 // per-lane traversal stack: the first LDS_STACK_DEPTH entries in LDS (entries of one lane are 64 dwords apart:
 // conflict-free), deeper entries in a global spill array indexed [entry][queue slot] (touched only by the rare deep
-// path; a private array would be promoted to 32 VGPRs or drag the stack pointer into scratch).
+// path; a private array would be promoted to 32 VGPRs or drag the stack pointer into scratch).  top() and put() touch
+// LDS unconditionally -- indices past the LDS part go to the dump row -- so that the common case has no branch.
 struct LaneStack {
     RT_LDS int* lds;
     RT_GLOBAL int* spill;   // &stack_spill[queue slot]
     u32 spill_stride;
     int sp;
-    RT_DEV void push(int v) {
-        if (sp < LDS_STACK_DEPTH) lds[sp * TRAVERSE_WAVE] = v;
-        else if (sp < LDS_STACK_DEPTH + OVF_STACK_DEPTH) spill[(size_t) (sp - LDS_STACK_DEPTH) * spill_stride] = v;
-        sp++;
+    RT_DEV void reset() { lds[0] = RT_TRAVERSAL_DONE; sp = 1; }
+    RT_DEV int top() const { // the entry a pop would return; sp >= 1 while the ray runs
+        const int i = sp - 1;
+        int v = lds[(i < LDS_STACK_DEPTH ? i : LDS_STACK_DEPTH) * TRAVERSE_WAVE];
+        if (i >= LDS_STACK_DEPTH) v = i < LDS_STACK_DEPTH + OVF_STACK_DEPTH ? spill[(size_t) (i - LDS_STACK_DEPTH) * spill_stride] : RT_TRAVERSAL_DONE;
+        return v;
     }
-    RT_DEV int pop() {
-        sp--;
-        if (sp < LDS_STACK_DEPTH) return lds[sp * TRAVERSE_WAVE];
-        if (sp < LDS_STACK_DEPTH + OVF_STACK_DEPTH) return spill[(size_t) (sp - LDS_STACK_DEPTH) * spill_stride];
-        return RT_STACK_MARKER; // unreachable when the host-side depth check holds
+    RT_DEV void put(int v, bool keep) { // stores above the top without moving sp; `keep` = the caller will count it in
+        const int i = sp;
+        lds[(i < LDS_STACK_DEPTH ? i : LDS_STACK_DEPTH) * TRAVERSE_WAVE] = v;
+        if (i >= LDS_STACK_DEPTH && keep && i < LDS_STACK_DEPTH + OVF_STACK_DEPTH) spill[(size_t) (i - LDS_STACK_DEPTH) * spill_stride] = v;
     }
-    RT_DEV bool empty() const { return sp == 0; }
+    RT_DEV void push(int v) { put(v, true); sp++; }
+    RT_DEV int pop() { int v = top(); sp--; return v; }
 };
 
 // rank of this thread among the threads of its 1024-thread workgroup with pred set, and their total
@@ -205,7 +208,7 @@ RT_DEV void traverse_counters_flush(const PassArgs& a, const TraverseCounters& c
 // PRIMARY: bounce 0 of the camera pass; lane t traces the primary ray of thread_pixel(t), the hit goes to slot t.
 template <bool COUNT, int WAVES_PER_SIMD, bool PRIMARY>
 __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq, u32 sample_index) {
-    __shared__ int smem[LDS_STACK_DEPTH * TRAVERSE_WAVE];
+    __shared__ int smem[(LDS_STACK_DEPTH + 1) * TRAVERSE_WAVE];
     const u32 qi = blockIdx.x * TRAVERSE_WAVE + threadIdx.x;
     bool active;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
     TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
     if (active) {
         LaneStack st; st.lds = (RT_LDS int*) &smem[threadIdx.x]; st.spill = (RT_GLOBAL int*) (a.stack_spill + qi);
-        st.spill_stride = a.n_paths; st.sp = 0;
+        st.spill_stride = a.n_paths; st.sp = 1;
         TraceState S;
         trace_begin(a.scene, o, d, a.tmax, S);
         trace_run<LaneStack, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, S, cnt);

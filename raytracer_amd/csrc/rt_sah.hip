@@ -47,9 +47,9 @@ RT_DEV int sah_bin_of(float c, float lo, float hi) {
     return b < 0 ? 0 : (b > NBINS - 1 ? NBINS - 1 : b);
 }
 
-__global__ void k_sah_clear(SahBin* __restrict__ bins, u32 n_bins) {
+__global__ void k_sah_clear(SahBin* __restrict__ bins, const u32* __restrict__ counters) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_bins) return;
+    if (i >= counters[0] * 3u * NBINS) return; // the bins of this level's tasks
     SahBin b; b.n = 0; b.pad = 0;
     for (int k = 0; k < 3; k++) { b.lo[k] = 0xffffffffu; b.hi[k] = 0u; }
     bins[i] = b;
@@ -292,18 +292,22 @@ int sah_build(hipStream_t s, LbvhWorkspace& w, SahWorkspace& sw, u32 n, int leaf
     RT_HIP(hipMemcpyAsync((char*) sw.tasks[0] + offsetof(SahTask, lo), w.scene_box, sizeof(Aabb), hipMemcpyDeviceToDevice, s)); // root box
     u32* idx[2] = { w.vals, w.vals_tmp }; u32* slot[2] = { w.keys, w.keys_tmp };
     hipLaunchKernelGGL(k_sah_init, grid_for(n), dim3(BT), 0, s, w.boxes, n, idx[0], slot[0], (SahTask*) sw.tasks[0], sw.counters);
+    // The host reads the task count back only every fourth level (a read-back is a stream synchronisation); the kernels
+    // take it from device memory, so the up to three levels launched after the tree has closed are no-ops.
     u32 n_tasks = 1; int cur = 0;
     for (int level = 0; level < 96 && n_tasks > 0; level++) {
-        hipLaunchKernelGGL(k_sah_clear, grid_for(n_tasks * 3 * NBINS), dim3(BT), 0, s, (SahBin*) sw.bins, n_tasks * 3 * NBINS);
+        const u32 task_bound = level < 20 ? ((1u << level) < n ? (1u << level) : n) : n; // a level has at most 2^level tasks
+        hipLaunchKernelGGL(k_sah_clear, grid_for(task_bound * 3 * NBINS), dim3(BT), 0, s, (SahBin*) sw.bins, (const u32*) sw.counters);
         hipLaunchKernelGGL(k_sah_bin, grid_for(n), dim3(BT), 0, s, w.boxes, idx[cur], slot[cur], n, (const SahTask*) sw.tasks[cur], (SahBin*) sw.bins);
         hipLaunchKernelGGL(k_sah_split, dim3(1), dim3(1024), 0, s, (const SahTask*) sw.tasks[cur], (const SahBin*) sw.bins,
                            (SahDecision*) sw.decisions, (SahTask*) sw.tasks[cur ^ 1], nodes_out, sw.counters, sah_tri, leaf_max);
         hipLaunchKernelGGL(k_sah_move, grid_for(n), dim3(BT), 0, s, w.boxes, idx[cur], slot[cur], n, (const SahTask*) sw.tasks[cur],
                            (SahDecision*) sw.decisions, (SahTask*) sw.tasks[cur ^ 1], idx[cur ^ 1], slot[cur ^ 1]);
-        RT_HIP(hipMemcpyAsync(&n_tasks, sw.counters, 4, hipMemcpyDeviceToHost, s));
-        RT_HIP(hipStreamSynchronize(s));
-        if (n_tasks > sw.capacity) { set_error("sah_build: %u tasks exceed the workspace", n_tasks); return RT_ERR_LIMIT; }
         cur ^= 1;
+        if ((level & 3) == 3) {
+            RT_HIP(hipMemcpyAsync(&n_tasks, sw.counters, 4, hipMemcpyDeviceToHost, s));
+            RT_HIP(hipStreamSynchronize(s));
+        }
     }
     if (n_tasks != 0) { set_error("sah_build: the tree did not close after 96 levels"); return RT_ERR_LIMIT; }
     // cost first: k_sah_finish rewrites the leaf links of a top-level tree (counters[3] holds the cost as a float)
