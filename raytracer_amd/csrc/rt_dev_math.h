@@ -163,7 +163,9 @@ RT_DEV RayPrep prepare_ray(f3 o, f3 d) {
     return r;
 }
 
-RT_DEV bool intersect_triangle(const RayPrep& r, f3 p0, f3 p1, f3 p2, float& t_out, float& u_out, float& v_out) {
+// The barycentrics of a candidate are returned as the numerators V, W and the denominator det: only the closest hit
+// of a ray needs u = V / det and v = W / det, so the caller divides once per ray (same operands, same quotient).
+RT_DEV bool intersect_triangle(const RayPrep& r, f3 p0, f3 p1, f3 p2, float& t_out, float& v_num, float& w_num, float& det_out) {
     f3 A = p0 - r.o, B = p1 - r.o, C = p2 - r.o;
     float Akz = comp3(A, r.kz), Bkz = comp3(B, r.kz), Ckz = comp3(C, r.kz);
     float Ax = comp3(A, r.kx) - r.sx * Akz, Ay = comp3(A, r.ky) - r.sy * Akz;
@@ -186,8 +188,7 @@ RT_DEV bool intersect_triangle(const RayPrep& r, f3 p0, f3 p1, f3 p2, float& t_o
     float Az = r.sz * Akz, Bz = r.sz * Bkz, Cz = r.sz * Ckz;
     float T = U * Az + V * Bz + W * Cz;
     t_out = T / det;
-    u_out = V / det;
-    v_out = W / det;
+    v_num = V; w_num = W; det_out = det;
     return true;
 }
 

@@ -59,42 +59,56 @@ RT_DEV bool first_active_lane() {
 }
 
 // parameters of the (non-spec, conservative) ray/box test for one level
+//
+// Per axis k the ray enters a slab through its plane on the side the ray comes from and leaves through the other one;
+// which is which depends only on the sign of d_k, so the two planes are picked with a select and each distance is one
+// fused multiply-add,  near_k = P_near * (1/d_k) + cn_k,   far_k = P_far * (1/d_k) + cf_k,
+// with cn_k = -(o_k / d_k) - pad_k and cf_k = -(o_k / d_k) + pad_k.  17 vector instructions per box; the form
+// (P - o) * (1/d) with min / max per axis and the padding applied afterwards took 27.
+//
+// pad_k makes the test conservative:
+//  * 2^-21 (|o_k| + bound) |1/d_k| covers the rounding of this test itself.  |P| <= bound (the largest coordinate of
+//    the level's boxes), so |P - o_k| |1/d_k| <= (bound + |o_k|) |1/d_k|; the reciprocal is good to 2^-23 relative, the
+//    product o_k * (1/d_k), the constant and the fused multiply-add to 2^-24 each of a quantity no larger than that:
+//    1.25 * 2^-22 in all.
+//  * 4e-6 (bound + max|o|) / max|d| covers the rounding of the *triangle* test, whose t is a quotient of sums of terms
+//    of size (extent + |o|) / max|d| (S4): two hits closer together than that may order differently than their boxes.
+// A zero component of d gives 1/d_k = +-1e18 instead of +-inf: nothing overflows or turns into NaN for coordinates
+// below 1e20, the slab still says "inside" or "outside" to within pad_k, and no ray can pass every box (a NaN or
+// infinite box distance used to let one ray in ~8 M walk a whole 52 k-instance TLAS and hold a launch for 30 ms).
 struct BoxRay {
-    float idx, idy, idz;   // 1 / d  (+-inf for a zero component: the slab then only says inside / outside)
-    float ox, oy, oz;      // origin
-    float pad;             // absolute padding in t
+    float idx, idy, idz;   // 1 / d, magnitude clamped to 1e18
+    float cnx, cny, cnz;   // constants of the entry distances
+    float cfx, cfy, cfz;   // constants of the exit distances
+    bool px, py, pz;       // 1/d_k >= 0: the ray enters slab k through its lower plane
 };
 
-// Slab distances are (plane - origin) * (1/d): the subtraction is exact to half an ulp of its result, so a relative
-// pad covers the rounding of the box test itself, whatever the size of 1/d.  The absolute pad covers the rounding of
-// the *triangle* test, whose t is a quotient of sums of terms of size (extent + |o|) / max|d| (S4): two hits closer
-// together than that may order differently than their boxes do.
+#define RT_BOX_ID_LIMIT 1.0e18f
 RT_DEV BoxRay make_box_ray(f3 o, f3 d, float bound) {
     BoxRay b;
-    b.idx = fast_rcp(d.x); b.idy = fast_rcp(d.y); b.idz = fast_rcp(d.z);
-    b.ox = o.x; b.oy = o.y; b.oz = o.z;
-    float omax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-    float imin = fminf(fminf(fabsf(b.idx), fabsf(b.idy)), fabsf(b.idz)); // 1 / largest |component of d|
-    b.pad = 4.0e-6f * (bound + omax) * imin;
+    b.idx = fminf(fmaxf(fast_rcp(d.x), -RT_BOX_ID_LIMIT), RT_BOX_ID_LIMIT);
+    b.idy = fminf(fmaxf(fast_rcp(d.y), -RT_BOX_ID_LIMIT), RT_BOX_ID_LIMIT);
+    b.idz = fminf(fmaxf(fast_rcp(d.z), -RT_BOX_ID_LIMIT), RT_BOX_ID_LIMIT);
+    b.px = b.idx >= 0.0f; b.py = b.idy >= 0.0f; b.pz = b.idz >= 0.0f;
+    const float omax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+    const float imin = fminf(fminf(fabsf(b.idx), fabsf(b.idy)), fabsf(b.idz)); // 1 / largest |component of d|
+    const float pad = 4.0e-6f * (bound + omax) * imin;
+    const float padx = __builtin_fmaf(4.77e-7f * (fabsf(o.x) + bound), fabsf(b.idx), pad);
+    const float pady = __builtin_fmaf(4.77e-7f * (fabsf(o.y) + bound), fabsf(b.idy), pad);
+    const float padz = __builtin_fmaf(4.77e-7f * (fabsf(o.z) + bound), fabsf(b.idz), pad);
+    const float ox = o.x * b.idx, oy = o.y * b.idy, oz = o.z * b.idz;
+    b.cnx = -ox - padx; b.cny = -oy - pady; b.cnz = -oz - padz;
+    b.cfx = padx - ox;  b.cfy = pady - oy;  b.cfz = padz - oz;
     return b;
 }
 
-// returns entry distance; hit iff entry <= exit.  NaNs (0 * inf: origin exactly on a plane of a slab the ray is
-// parallel to) are dropped by min/max, which keeps the test conservative.  A ray parallel to a slab and outside it
-// gives +-inf for both planes; the per-axis clamps (free: min3 / max3) keep those finite so that the padding below
-// cannot turn them into inf - inf = NaN, which would pass the box (seen: one such ray per ~8 M walked most of a
-// 52 k-instance TLAS and held a launch for 30 ms).
-#define RT_BOX_T_LIMIT 3.0e38f
+// hit iff the padded slab intervals and [tmin, tmax] have a common point; `entry` orders the two children of a node
 RT_DEV bool box_test(const BoxRay& r, const float* lo, const float* hi, float tmin, float tmax, float& entry) {
-    float t0x = (lo[0] - r.ox) * r.idx, t1x = (hi[0] - r.ox) * r.idx;
-    float t0y = (lo[1] - r.oy) * r.idy, t1y = (hi[1] - r.oy) * r.idy;
-    float t0z = (lo[2] - r.oz) * r.idz, t1z = (hi[2] - r.oz) * r.idz;
-    float nx = fminf(fminf(t0x, t1x), RT_BOX_T_LIMIT), ny = fminf(fminf(t0y, t1y), RT_BOX_T_LIMIT), nz = fminf(fminf(t0z, t1z), RT_BOX_T_LIMIT);
-    float fx = fmaxf(fmaxf(t0x, t1x), -RT_BOX_T_LIMIT), fy = fmaxf(fmaxf(t0y, t1y), -RT_BOX_T_LIMIT), fz = fmaxf(fmaxf(t0z, t1z), -RT_BOX_T_LIMIT);
-    float tn = fmaxf(fmaxf(nx, ny), nz);
-    float tf = fminf(fminf(fx, fy), fz);
-    tn = __builtin_fmaf(fabsf(tn), -2.0e-6f, tn - r.pad);
-    tf = __builtin_fmaf(fabsf(tf), 2.0e-6f, tf + r.pad);
+    const float nx = __builtin_fmaf(r.px ? lo[0] : hi[0], r.idx, r.cnx), fx = __builtin_fmaf(r.px ? hi[0] : lo[0], r.idx, r.cfx);
+    const float ny = __builtin_fmaf(r.py ? lo[1] : hi[1], r.idy, r.cny), fy = __builtin_fmaf(r.py ? hi[1] : lo[1], r.idy, r.cfy);
+    const float nz = __builtin_fmaf(r.pz ? lo[2] : hi[2], r.idz, r.cnz), fz = __builtin_fmaf(r.pz ? hi[2] : lo[2], r.idz, r.cfz);
+    const float tn = fmaxf(fmaxf(nx, ny), nz);
+    const float tf = fminf(fminf(fx, fy), fz);
     entry = tn;
     return fmaxf(tn, tmin) <= fminf(tf, tmax);
 }
@@ -116,6 +130,7 @@ struct TraceState {
     bool have_hit, bottom;
     int cur_inst;  // instance being traversed (bottom level)
     int cur;       // node link in hand, RT_TRAVERSAL_DONE when the ray is finished
+    float det;     // denominator of best.u / best.v, which hold the numerators until the ray is finished
     const RT_GLOBAL BvhNode* nodes;
     const RT_GLOBAL TriRec* tris;
     BoxRay br;
@@ -146,13 +161,15 @@ RT_DEV void trace_bottom_level(const SceneView& sc, f3 o, f3 d, TraceState& S) {
 
 RT_DEV void trace_begin(const SceneView& sc, f3 o, f3 d, float tmax, TraceState& S) {
     S.best.t = tmax; S.best.u = 0.0f; S.best.v = 0.0f; S.best.inst = -1; S.best.tri = -1; S.best.prim_global = 0;
-    S.have_hit = false; S.cur_inst = -1; S.tris = nullptr;
+    S.have_hit = false; S.cur_inst = -1; S.tris = nullptr; S.det = 1.0f;
     S.rp.o = o; S.rp.kx = 0; S.rp.ky = 1; S.rp.kz = 2; S.rp.sx = S.rp.sy = S.rp.sz = 0.0f;
     trace_top_level(sc, o, d, S);
     // a NaN in the ray makes every triangle test fail (S4 compares with NaN are false): the answer is a miss, and
     // it must not cost a walk through the whole tree (NaN box tests pass conservatively).  Such rays do occur:
     // a shading normal perpendicular to the ray is scaled by sign(0) = 0 (raytracing.hlsl:64-65).
-    bool finite = o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z;
+    // (an infinite component would put NaNs into the box test: every triangle test fails on it as well)
+    const float big = 3.0e38f;
+    bool finite = fabsf(o.x) <= big && fabsf(o.y) <= big && fabsf(o.z) <= big && fabsf(d.x) <= big && fabsf(d.y) <= big && fabsf(d.z) <= big;
     S.cur = finite ? 0 : RT_TRAVERSAL_DONE;
 }
 
@@ -182,7 +199,7 @@ RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, S
             const bool h0 = box_test(S.br, lo0, hi0, tmin, S.best.t, e0);
             const bool h1 = box_test(S.br, lo1, hi1, tmin, S.best.t, e1);
             const int c0 = (int) as_u32(q3.x), c1 = (int) as_u32(q3.y);
-            const bool both = h0 & h1, any = h0 | h1, first0 = e0 <= e1;
+            const bool both = h0 && h1, any = h0 || h1, first0 = e0 <= e1;
             st.put(first0 ? c1 : c0, both);       // the far child, kept only when both boxes are hit
             int next = h0 ? c0 : c1;              // the only child hit ...
             next = both ? (first0 ? c0 : c1) : next; // ... or the nearer of the two
@@ -209,22 +226,23 @@ RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, S
                 const RT_GLOBAL TriRec* tr = S.tris + first + k;
                 Quad a = ldq(tr, 0), b = ldq(tr, 1), c = ldq(tr, 2);
                 if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
-                float t, u, w;
-                if (!intersect_triangle(S.rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, w)) continue;
-                if (!(t > tmin && t < tmax)) continue;
-                u32 prim_global = as_u32(c.y);
-                bool better = t < S.best.t;
-                if (!better && S.have_hit && t == S.best.t)
-                    better = S.cur_inst < S.best.inst || (S.cur_inst == S.best.inst && prim_global < S.best.prim_global);
-                if (better) {
-                    S.best.t = t; S.best.u = u; S.best.v = w; S.best.inst = S.cur_inst; S.best.tri = first + k;
+                float t = 0.0f, vn = 0.0f, wn = 0.0f, det = 1.0f;
+                const bool hit = intersect_triangle(S.rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, vn, wn, det);
+                const u32 prim_global = as_u32(c.y);
+                // closest hit, ties to the lowest (instance, primitive); written without short-circuit branches
+                const bool in_range = (t > tmin) & (t < tmax);
+                const bool first_of_tie = (S.cur_inst < S.best.inst) | ((S.cur_inst == S.best.inst) & (prim_global < S.best.prim_global));
+                const bool better = (t < S.best.t) | (S.have_hit & (t == S.best.t) & first_of_tie);
+                if (hit & in_range & better) {
+                    S.best.t = t; S.best.u = vn; S.best.v = wn; S.det = det; S.best.inst = S.cur_inst; S.best.tri = first + k;
                     S.best.prim_global = prim_global; S.have_hit = true;
                 }
             }
             S.cur = st.pop();
         }
     }
-    if (!S.have_hit) S.best.t = inf_f32();
+    if (S.have_hit) { S.best.u = S.best.u / S.det; S.best.v = S.best.v / S.det; } // S4: u = V / det, v = W / det
+    else S.best.t = inf_f32();
 }
 
 } // namespace rtd
