@@ -229,6 +229,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_trav * rays_per_launch,
                          "bytes_per_ray_traverse": b_trav, "bytes_per_ray_pipeline": b_ray,
+                         # what this implementation's records actually are (32-byte packed nodes, 48-byte triangles,
+                         # 96-byte instance records) times its own trees' counts; the figure above is SURVEY 8(d)'s model
+                         "bytes_per_ray_traverse_this_layout": 52.0 + 32.0 * gpu_counts["n_node"] + 48.0 * gpu_counts["n_tri"] + 96.0 * gpu_counts["n_inst"],
                          "mean_launch_ms": mean_launch_ms, "rays_per_launch": rays_per_launch,
                          "traverse_Mrays_s": rays / (stats["traverse_ms"] * 1e-3) / 1e6 if stats["traverse_ms"] > 0 else None,
                          "model_counts": model, "gpu_bvh_counts": gpu_counts},

@@ -34,7 +34,7 @@ struct TranslucentMesh { // raytracing.cpp:49-53 + BluenoisePreprocess (bluenois
 
 struct Blas {
     RtVertex* d_verts = nullptr; uint16_t* d_indices = nullptr; GeomRec* d_geoms = nullptr; u32* d_tri_geometry = nullptr;
-    BvhNode* d_nodes = nullptr; TriRec* d_tris = nullptr; /* inside the d_nodes allocation */ u32* d_perm = nullptr; float bound = 0;
+    PackedNode* d_nodes = nullptr; TriRec* d_tris = nullptr; /* inside the d_nodes allocation */ u32* d_perm = nullptr; TreeInfo info = {};
     std::vector<RtVertex> verts; std::vector<uint16_t> indices; std::vector<GeomRec> geoms;
     u32 n_tris = 0; int depth = 0;
     u32 translucent_ids_index = 0, translucent_ids_count = 0;
@@ -62,7 +62,7 @@ struct rt_ctx {
     std::vector<TranslucentInstance> translucent_instances;
     // TLAS
     u32 n_instances = 0;
-    InstRec* d_inst_rec = nullptr; InstShade* d_inst_shade = nullptr; BvhNode* d_tlas_nodes = nullptr; u32* d_tlas_perm = nullptr;
+    InstRec* d_inst_rec = nullptr; InstShade* d_inst_shade = nullptr; PackedNode* d_tlas_nodes = nullptr; TreeInfo tlas_info = {}; u32* d_tlas_perm = nullptr;
     int tlas_depth = 0;
     // translucent sample points, all instances concatenated
     u32 n_points = 0;
@@ -162,6 +162,8 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.tmin = probe ? 0.0001f : 0.000001f; // raytracing.hlsl:249 / :133
     a.tmax = 10000.0f;
     a.scene.tlas_nodes = c->d_tlas_nodes; a.scene.insts = c->d_inst_rec;
+    for (int k = 0; k < 3; k++) { a.scene.tlas_ctr[k] = c->tlas_info.ctr[k]; a.scene.tlas_inv_h[k] = c->tlas_info.inv_h[k]; }
+    a.scene.tlas_bound = c->tlas_info.bound;
     a.shade.insts = c->d_inst_shade; a.shade.slot_to_ti = c->d_slot_to_ti; a.shade.slot_count = c->slot_count;
     a.shade.slices = c->d_slices;
     a.q[0] = c->q[0]; a.q[1] = c->q[1]; a.hits = c->hits; a.ps = c->ps; a.gq = c->gq;
@@ -440,7 +442,7 @@ int rt_build_blas(rt_ctx* c, const RtGeometry* geometries, int n, rt_blas* out) 
     RT_HIP(hipMalloc(&b.d_geoms, b.geoms.size() * sizeof(GeomRec)));
     RT_HIP(hipMalloc(&b.d_tri_geometry, tri_geometry.size() * 4));
     // nodes and triangles share one allocation: an instance record addresses both with one pointer + a 32-bit offset
-    RT_HIP(hipMalloc(&b.d_nodes, n_nodes * sizeof(BvhNode) + b.n_tris * sizeof(TriRec)));
+    RT_HIP(hipMalloc(&b.d_nodes, n_nodes * sizeof(PackedNode) + b.n_tris * sizeof(TriRec)));
     b.d_tris = (TriRec*) (b.d_nodes + n_nodes);
     RT_HIP(hipMalloc(&b.d_perm, b.n_tris * 4));
     RT_HIP(hipMemcpyAsync(b.d_verts, b.verts.data(), b.verts.size() * sizeof(RtVertex), hipMemcpyHostToDevice, c->stream));
@@ -453,13 +455,12 @@ int rt_build_blas(rt_ctx* c, const RtGeometry* geometries, int n, rt_blas* out) 
     rc = lbvh_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, b.n_tris, RT_LEAF_MAX_TRIS, false, b.d_nodes, b.d_perm); if (rc) return rc;
     rc = lbvh_write_trirecs(c->stream, b.d_perm, b.d_verts, b.d_indices, b.d_tri_geometry, b.d_geoms, b.n_tris, b.d_tris); if (rc) return rc;
     RT_HIP(hipEventRecord(e1, c->stream));
-    BvhNode root;
-    RT_HIP(hipMemcpyAsync(&root, b.d_nodes, sizeof root, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(hipMemcpyAsync(&b.info, c->lbvh.tree_info, sizeof b.info, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream)); // host arrays are borrowed only for this call
     float ms = 0; RT_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     c->blas_build_ms = ms;
-    b.depth = root.depth; b.bound = root.bound;
+    b.depth = b.info.depth;
     c->blas_triangles += b.n_tris;
     for (auto& m : new_meshes) { c->translucent_meshes.push_back(m); c->translucent_mean_area.push_back(0.0f); }
     c->blas.push_back(std::move(b));
@@ -495,7 +496,9 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
             c->g.translucent_instance_stride = std::max(c->g.translucent_instance_stride, counts[instances[i].blas]);
         }
         invert_affine(instances[i].transform, rec[i].world_to_object);
-        rec[i].nodes = b.d_nodes; rec[i].tris_offset = (u32) ((const char*) b.d_tris - (const char*) b.d_nodes); rec[i].bound = b.bound;
+        rec[i].nodes = b.d_nodes; rec[i].tris_offset = (u32) ((const char*) b.d_tris - (const char*) b.d_nodes); rec[i].bound = b.info.bound;
+        for (int k = 0; k < 3; k++) { rec[i].ctr[k] = b.info.ctr[k]; rec[i].inv_h[k] = b.info.inv_h[k]; }
+        rec[i].pad[0] = rec[i].pad[1] = 0.0f;
         memcpy(shade[i].object_to_world, instances[i].transform, 64);
         shade[i].vertices = b.d_verts; shade[i].indices = b.d_indices; shade[i].geoms = b.d_geoms; shade[i].tris = b.d_tris;
         shade[i].instance_id = instance_id; shade[i].vertex_count = (u32) b.verts.size();
@@ -506,7 +509,7 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
     u32 n_nodes = n > 1 ? (u32) n - 1 : 1;
     RT_HIP(hipMalloc(&c->d_inst_rec, sizeof(InstRec) * n));
     RT_HIP(hipMalloc(&c->d_inst_shade, sizeof(InstShade) * n));
-    RT_HIP(hipMalloc(&c->d_tlas_nodes, sizeof(BvhNode) * n_nodes));
+    RT_HIP(hipMalloc(&c->d_tlas_nodes, sizeof(PackedNode) * n_nodes));
     RT_HIP(hipMalloc(&c->d_tlas_perm, 4 * (size_t) n));
     RT_HIP(hipMemcpyAsync(c->d_inst_rec, rec.data(), sizeof(InstRec) * n, hipMemcpyHostToDevice, c->stream));
     RT_HIP(hipMemcpyAsync(c->d_inst_shade, shade.data(), sizeof(InstShade) * n, hipMemcpyHostToDevice, c->stream));
@@ -518,13 +521,12 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
     rc = lbvh_instance_boxes(c->stream, c->lbvh, c->d_inst_shade, c->d_inst_rec, (u32) n, exact_boxes); if (rc) return rc;
     rc = lbvh_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, (u32) n, 1, true, c->d_tlas_nodes, c->d_tlas_perm); if (rc) return rc;
     RT_HIP(hipEventRecord(e1, c->stream));
-    BvhNode root;
-    RT_HIP(hipMemcpyAsync(&root, c->d_tlas_nodes, sizeof root, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(hipMemcpyAsync(&c->tlas_info, c->lbvh.tree_info, sizeof c->tlas_info, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
     float ms = 0; RT_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     c->tlas_build_ms = ms;
-    c->tlas_depth = root.depth;
+    c->tlas_depth = c->tlas_info.depth;
     c->n_instances = (u32) n;
     if (c->tlas_depth + 1 + max_blas_depth > 64) {
         set_error("rt_build_tlas: BVH too deep for the traversal stack (tlas %d + blas %d)", c->tlas_depth, max_blas_depth);

@@ -56,12 +56,11 @@ __global__ void k_instance_boxes(const InstShade* __restrict__ shade, const Inst
                                  Aabb* __restrict__ boxes) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const BvhNode& root = insts[i].nodes[0];
-    // object-space box of the whole BLAS = union of the root's two child boxes
+    // object-space box of the whole BLAS, back from the frame of its packed nodes (a shade generous)
     float lo[3], hi[3];
     for (int k = 0; k < 3; k++) {
-        lo[k] = root.lo0[k]; hi[k] = root.hi0[k];
-        if (root.lo1[k] != RT_EMPTY_COORD) { lo[k] = fminf(lo[k], root.lo1[k]); hi[k] = fmaxf(hi[k], root.hi1[k]); }
+        float h = 1.00001f / insts[i].inv_h[k];
+        lo[k] = insts[i].ctr[k] - h; hi[k] = insts[i].ctr[k] + h;
     }
     Aabb b;
     for (int k = 0; k < 3; k++) { b.lo[k] = 3.4e38f; b.hi[k] = -3.4e38f; }
@@ -241,13 +240,15 @@ int lbvh_workspace_reserve(LbvhWorkspace& w, u32 n) {
     RT_HIP(hipMalloc(&w.cost, 4 * (size_t) cap));
     RT_HIP(hipMalloc(&w.collapsed, 4 * (size_t) cap));
     RT_HIP(hipMalloc(&w.sort_scratch, sort_scratch_bytes(cap)));
+    RT_HIP(hipMalloc(&w.tree_nodes, sizeof(BvhNode) * cap));
+    RT_HIP(hipMalloc(&w.tree_info, sizeof(TreeInfo)));
     w.capacity = cap;
     return RT_OK;
 }
 
 void lbvh_workspace_free(LbvhWorkspace& w) {
     void* ptrs[] = { w.boxes, w.node_boxes, w.scene_box, w.keys, w.vals, w.keys_tmp, w.vals_tmp, w.build_nodes,
-                     w.leaf_parent, w.flags, w.depth, w.cost, w.collapsed, w.sort_scratch };
+                     w.leaf_parent, w.flags, w.depth, w.cost, w.collapsed, w.sort_scratch, w.tree_nodes, w.tree_info };
     for (void* p : ptrs) if (p) (void) hipFree(p);
     w = LbvhWorkspace();
 }
@@ -267,7 +268,75 @@ int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const InstShade* shade,
     return RT_OK;
 }
 
-int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace* sw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, BvhNode* nodes_out, u32* perm_out) {
+// ---- packing: 64-byte build nodes -> 32-byte traversal nodes (PackedNode, rt_dev_scene.h) ---------------------------
+// frame of a tree: centre and reciprocal half extent of its box.  A flat or very thin axis is scaled as if it were
+// 1/4096 of the widest one (its planes then sit near q = 0, where halves are densest), so that rays keep ordinary
+// magnitudes in the frame.
+RT_DEV void tree_frame(const Aabb& box, float* ctr, float* inv_h) {
+    float h[3], hmax = 0.0f;
+    for (int k = 0; k < 3; k++) {
+        ctr[k] = 0.5f * box.lo[k] + 0.5f * box.hi[k];
+        h[k] = fmaxf(box.hi[k] - ctr[k], ctr[k] - box.lo[k]);
+        hmax = fmaxf(hmax, h[k]);
+    }
+    for (int k = 0; k < 3; k++) inv_h[k] = 1.0f / fmaxf(fmaxf(h[k], hmax * (1.0f / 4096.0f)), 1.0e-30f);
+}
+// largest half <= x / smallest half >= x
+RT_DEV u32 half_floor(float x) {
+    _Float16 h = (_Float16) x;
+    unsigned short u = __builtin_bit_cast(unsigned short, h);
+    if ((float) h > x) u = (u & 0x7fffu) == 0 ? (unsigned short) 0x8001u : ((u & 0x8000u) ? u + 1 : u - 1);
+    return u;
+}
+RT_DEV u32 half_ceil(float x) {
+    _Float16 h = (_Float16) x;
+    unsigned short u = __builtin_bit_cast(unsigned short, h);
+    if ((float) h < x) u = (u & 0x7fffu) == 0 ? (unsigned short) 0x0001u : ((u & 0x8000u) ? u - 1 : u + 1);
+    return u;
+}
+// planes of one child box on axis k in the frame, rounded outward; the float computation of q is itself good to a few
+// 2^-24 of (|q| + 1), far below the half spacing, and is pushed outward by 2^-20 (|q| + 1) before the rounding
+RT_DEV void pack_planes(float lo, float hi, float ctr, float inv_h, u32& qlo, u32& qhi) {
+    if (lo == RT_EMPTY_COORD) { qlo = 0x7c00u; qhi = 0x7c00u; return; } // absent child: +infinity
+    float a = (lo - ctr) * inv_h, b = (hi - ctr) * inv_h;
+    a -= 9.54e-7f * (fabsf(a) + 1.0f); b += 9.54e-7f * (fabsf(b) + 1.0f);
+    qlo = half_floor(a); qhi = half_ceil(b);
+}
+__global__ void k_pack_nodes(const Aabb* __restrict__ scene, const BvhNode* __restrict__ nodes, u32 n_nodes,
+                             PackedNode* __restrict__ out, TreeInfo* __restrict__ info) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    float ctr[3], inv_h[3];
+    tree_frame(*scene, ctr, inv_h);
+    const BvhNode nd = nodes[i];
+    u32 w[6];
+    for (int k = 0; k < 3; k++) {
+        u32 l0, h0, l1, h1;
+        pack_planes(nd.lo0[k], nd.hi0[k], ctr[k], inv_h[k], l0, h0);
+        pack_planes(nd.lo1[k], nd.hi1[k], ctr[k], inv_h[k], l1, h1);
+        w[2 * k] = l0 | (l1 << 16); w[2 * k + 1] = h0 | (h1 << 16);
+    }
+    PackedNode pn;
+    pn.lox = w[0]; pn.hix = w[1]; pn.loy = w[2]; pn.hiy = w[3]; pn.loz = w[4]; pn.hiz = w[5]; pn.c0 = nd.c0; pn.c1 = nd.c1;
+    out[i] = pn;
+    if (i == 0) {
+        TreeInfo t;
+        for (int k = 0; k < 3; k++) { t.ctr[k] = ctr[k]; t.inv_h[k] = inv_h[k]; }
+        t.bound = nd.bound; t.depth = nd.depth;
+        *info = t;
+    }
+}
+
+static int lbvh_build_impl(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace* sw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, BvhNode* nodes_out, u32* perm_out);
+int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace* sw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, PackedNode* nodes_out, u32* perm_out) {
+    int rc = lbvh_build_impl(s, w, pw, sw, builder, sah_tri, n, leaf_max, tlas, w.tree_nodes, perm_out);
+    if (rc != RT_OK) return rc;
+    const u32 n_nodes = n > 1 ? n - 1 : 1;
+    hipLaunchKernelGGL(k_pack_nodes, grid_for(n_nodes), dim3(BT), 0, s, w.scene_box, (const BvhNode*) w.tree_nodes, n_nodes, nodes_out, w.tree_info);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+static int lbvh_build_impl(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace* sw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, BvhNode* nodes_out, u32* perm_out) {
     if (n == 0 || n > w.capacity) { set_error("lbvh_build: bad primitive count %u", n); return RT_ERR_INVALID; }
     hipLaunchKernelGGL(k_scene_box, dim3(1), dim3(1024), 0, s, w.boxes, n, w.scene_box);
     hipLaunchKernelGGL(k_morton, grid_for(n), dim3(BT), 0, s, w.boxes, w.scene_box, n, w.keys, w.vals);

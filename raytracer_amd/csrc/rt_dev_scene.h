@@ -6,10 +6,11 @@
 
 namespace rtd {
 
-// 64 B: one binary BVH node = the boxes of its two children + two links.  Fetched as 4 x 16 B.
+// 64 B: one binary BVH node as the builders write it = the boxes of its two children + two links.
 //   link >= 0 : index of an internal node
 //   link <  0 : leaf.  BLAS: ~link = (first_tri << 3) | (tri_count - 1), TLAS: ~link = instance index
 //   an absent child has the box RT_EMPTY_BOX and is never entered
+// Traversal reads the 32-byte PackedNode made from it (below).
 struct alignas(16) BvhNode {
     float lo0[3], hi0[3], lo1[3], hi1[3];
     int   c0, c1;
@@ -20,6 +21,28 @@ struct alignas(16) BvhNode {
 #define RT_LEAF_MAX_TRIS 4
 #define RT_STACK_MARKER ((int) 0x80000000)
 
+// 32 B: the node traversal fetches (2 x 16 B instead of 4: for incoherent rays every 16-byte load of a lane is a
+// separate trip through the texture-address unit, which was ~70 % busy with the 64-byte node).  The planes of the two
+// child boxes are IEEE half floats in the tree's own frame q = (P - ctr) * inv_h (|q| <= 1 inside the tree's box), rounded
+// outward (lower planes down, upper planes up: the box only grows, the box test is conservative anyway).  Child 0 sits in
+// the low half of each word and child 1 in the high half, so one select per word picks the entry (or exit) plane of
+// both children and v_fma_mix_f32 converts the half while it computes the slab distance.  An absent child has
+// +infinity planes.  Measured cost of the 11-bit planes: nodes / triangles / instances per ray +0.1 % (bunny), +2 %
+// instance entries (52,743-instance field).
+struct alignas(16) PackedNode {
+    u32 lox, hix, loy, hiy, loz, hiz;
+    int c0, c1;
+};
+// frame of a tree + what the host needs to know about it (written by the packing kernel)
+struct TreeInfo {
+    float ctr[3], inv_h[3];
+    float bound;   // max |coordinate| of the tree in its own (object / world) space
+    int   depth;
+};
+typedef _Float16 rt_half2 __attribute__((ext_vector_type(2)));
+RT_DEV float half_lo(u32 w) { return (float) __builtin_bit_cast(rt_half2, w).x; }
+RT_DEV float half_hi(u32 w) { return (float) __builtin_bit_cast(rt_half2, w).y; }
+
 // 48 B: triangle in leaf order, fetched as 3 x 16 B
 struct alignas(16) TriRec {
     float v0[3], v1[3], v2[3];
@@ -28,17 +51,20 @@ struct alignas(16) TriRec {
     u32 prim_local;  // PrimitiveIndex()
 };
 
-// 64 B: what traversal needs per instance
+// 96 B: what traversal needs per instance (6 x 16 B)
 struct alignas(16) InstRec {
     float world_to_object[12]; // S7
-    const BvhNode* nodes;
+    const PackedNode* nodes;
     u32   tris_offset;         // byte offset of the BLAS's TriRec array from `nodes` (one allocation per BLAS)
-    float bound;               // nodes[0].bound, here so that entering an instance costs no dependent load
+    float bound;               // TreeInfo.bound of the BLAS, here so that entering an instance costs no dependent load
+    float ctr[3], inv_h[3];    // frame of the BLAS's packed nodes
+    float pad[2];
 };
 
 struct SceneView {
-    const BvhNode* tlas_nodes;
+    const PackedNode* tlas_nodes;
     const InstRec* insts;
+    float tlas_ctr[3], tlas_inv_h[3], tlas_bound;
 };
 
 struct HitOut {
@@ -60,57 +86,53 @@ RT_DEV bool first_active_lane() {
 
 // parameters of the (non-spec, conservative) ray/box test for one level
 //
-// Per axis k the ray enters a slab through its plane on the side the ray comes from and leaves through the other one;
-// which is which depends only on the sign of d_k, so the two planes are picked with a select and each distance is one
-// fused multiply-add,  near_k = P_near * (1/d_k) + cn_k,   far_k = P_far * (1/d_k) + cf_k,
-// with cn_k = -(o_k / d_k) - pad_k and cf_k = -(o_k / d_k) + pad_k.  17 vector instructions per box; the form
+// The test runs in the frame of the tree's packed nodes: q = (P - ctr) * inv_h per axis, an affine map per axis, which
+// keeps the ray parameter t.  Per axis k the ray enters a slab through its plane on the side the ray comes from and
+// leaves through the other one; which is which depends only on the sign of d_k, so the planes are picked with a select
+// (one per packed word, i.e. for both children at once) and each distance is one fused multiply-add,
+//     near_k = q_near * (1/d_k) + cn_k,   far_k = q_far * (1/d_k) + cf_k      (o, d in the frame)
+// with cn_k = -(o_k / d_k) - pad_k and cf_k = -(o_k / d_k) + pad_k: 14 vector instructions per box; the form
 // (P - o) * (1/d) with min / max per axis and the padding applied afterwards took 27.
 //
 // pad_k makes the test conservative:
-//  * 2^-21 (|o_k| + bound) |1/d_k| covers the rounding of this test itself.  |P| <= bound (the largest coordinate of
-//    the level's boxes), so |P - o_k| |1/d_k| <= (bound + |o_k|) |1/d_k|; the reciprocal is good to 2^-23 relative, the
-//    product o_k * (1/d_k), the constant and the fused multiply-add to 2^-24 each of a quantity no larger than that:
-//    1.25 * 2^-22 in all.
-//  * 4e-6 (bound + max|o|) / max|d| covers the rounding of the *triangle* test, whose t is a quotient of sums of terms
-//    of size (extent + |o|) / max|d| (S4): two hits closer together than that may order differently than their boxes.
-// A zero component of d gives 1/d_k = +-1e18 instead of +-inf: nothing overflows or turns into NaN for coordinates
-// below 1e20, the slab still says "inside" or "outside" to within pad_k, and no ray can pass every box (a NaN or
-// infinite box distance used to let one ray in ~8 M walk a whole 52 k-instance TLAS and hold a launch for 30 ms).
+//  * 2^-20 (|o_k| + 1) |1/d_k| covers the rounding of this test itself.  |q| <= 1, so |q - o_k| |1/d_k| <=
+//    (1 + |o_k|) |1/d_k|; origin and direction in the frame carry 2^-23 and 2^-24 relative, the reciprocal 2^-23, the
+//    product o_k * (1/d_k), the constant and the fused multiply-add 2^-24 each of a quantity no larger than that:
+//    2^-21 in all.
+//  * 4e-6 (bound + max|o|) / max|d| (object / world space quantities) covers the rounding of the *triangle* test, whose
+//    t is a quotient of sums of terms of size (extent + |o|) / max|d| (S4): two hits closer together than that may
+//    order differently than their boxes.
+// A zero component of d gives 1/d_k = +-1e18 instead of +-inf: nothing overflows or turns into NaN, the slab still says
+// "inside" or "outside" to within pad_k, and no ray can pass every box (a NaN or infinite box distance used to let one
+// ray in ~8 M walk a whole 52 k-instance TLAS and hold a launch for 30 ms).
 struct BoxRay {
-    float idx, idy, idz;   // 1 / d, magnitude clamped to 1e18
+    float idx, idy, idz;   // 1 / d in the frame, magnitude within [1e-30, 1e18]
     float cnx, cny, cnz;   // constants of the entry distances
     float cfx, cfy, cfz;   // constants of the exit distances
     bool px, py, pz;       // 1/d_k >= 0: the ray enters slab k through its lower plane
 };
 
 #define RT_BOX_ID_LIMIT 1.0e18f
-RT_DEV BoxRay make_box_ray(f3 o, f3 d, float bound) {
+RT_DEV float box_rcp(float d) {
+    float r = fminf(fmaxf(fast_rcp(d), -RT_BOX_ID_LIMIT), RT_BOX_ID_LIMIT);
+    return fabsf(r) >= 1.0e-30f ? r : copysignf(1.0e-30f, r); // never 0: an absent child's infinite planes must stay infinite
+}
+// o, d, bound: the level's own space (world or object); ctr, inv_h: the frame of its packed nodes
+RT_DEV BoxRay make_box_ray(f3 o, f3 d, float bound, f3 ctr, f3 inv_h) {
     BoxRay b;
-    b.idx = fminf(fmaxf(fast_rcp(d.x), -RT_BOX_ID_LIMIT), RT_BOX_ID_LIMIT);
-    b.idy = fminf(fmaxf(fast_rcp(d.y), -RT_BOX_ID_LIMIT), RT_BOX_ID_LIMIT);
-    b.idz = fminf(fmaxf(fast_rcp(d.z), -RT_BOX_ID_LIMIT), RT_BOX_ID_LIMIT);
-    b.px = b.idx >= 0.0f; b.py = b.idy >= 0.0f; b.pz = b.idz >= 0.0f;
     const float omax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-    const float imin = fminf(fminf(fabsf(b.idx), fabsf(b.idy)), fabsf(b.idz)); // 1 / largest |component of d|
-    const float pad = 4.0e-6f * (bound + omax) * imin;
-    const float padx = __builtin_fmaf(4.77e-7f * (fabsf(o.x) + bound), fabsf(b.idx), pad);
-    const float pady = __builtin_fmaf(4.77e-7f * (fabsf(o.y) + bound), fabsf(b.idy), pad);
-    const float padz = __builtin_fmaf(4.77e-7f * (fabsf(o.z) + bound), fabsf(b.idz), pad);
-    const float ox = o.x * b.idx, oy = o.y * b.idy, oz = o.z * b.idz;
+    const float dmax = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    const float pad = 4.0e-6f * (bound + omax) * fminf(fast_rcp(dmax), RT_BOX_ID_LIMIT);
+    const f3 oq = (o - ctr) * inv_h, dq = d * inv_h;
+    b.idx = box_rcp(dq.x); b.idy = box_rcp(dq.y); b.idz = box_rcp(dq.z);
+    b.px = b.idx >= 0.0f; b.py = b.idy >= 0.0f; b.pz = b.idz >= 0.0f;
+    const float padx = __builtin_fmaf(9.54e-7f * (fabsf(oq.x) + 1.0f), fabsf(b.idx), pad);
+    const float pady = __builtin_fmaf(9.54e-7f * (fabsf(oq.y) + 1.0f), fabsf(b.idy), pad);
+    const float padz = __builtin_fmaf(9.54e-7f * (fabsf(oq.z) + 1.0f), fabsf(b.idz), pad);
+    const float ox = oq.x * b.idx, oy = oq.y * b.idy, oz = oq.z * b.idz;
     b.cnx = -ox - padx; b.cny = -oy - pady; b.cnz = -oz - padz;
     b.cfx = padx - ox;  b.cfy = pady - oy;  b.cfz = padz - oz;
     return b;
-}
-
-// hit iff the padded slab intervals and [tmin, tmax] have a common point; `entry` orders the two children of a node
-RT_DEV bool box_test(const BoxRay& r, const float* lo, const float* hi, float tmin, float tmax, float& entry) {
-    const float nx = __builtin_fmaf(r.px ? lo[0] : hi[0], r.idx, r.cnx), fx = __builtin_fmaf(r.px ? hi[0] : lo[0], r.idx, r.cfx);
-    const float ny = __builtin_fmaf(r.py ? lo[1] : hi[1], r.idy, r.cny), fy = __builtin_fmaf(r.py ? hi[1] : lo[1], r.idy, r.cfy);
-    const float nz = __builtin_fmaf(r.pz ? lo[2] : hi[2], r.idz, r.cnz), fz = __builtin_fmaf(r.pz ? hi[2] : lo[2], r.idz, r.cfz);
-    const float tn = fmaxf(fmaxf(nx, ny), nz);
-    const float tf = fminf(fminf(fx, fy), fz);
-    entry = tn;
-    return fmaxf(tn, tmin) <= fminf(tf, tmax);
 }
 
 // 16-byte loads: nodes, triangles and instance records are fetched as whole 16-byte quads (coalescer-friendly,
@@ -131,31 +153,30 @@ struct TraceState {
     int cur_inst;  // instance being traversed (bottom level)
     int cur;       // node link in hand, RT_TRAVERSAL_DONE when the ray is finished
     float det;     // denominator of best.u / best.v, which hold the numerators until the ray is finished
-    const RT_GLOBAL BvhNode* nodes;
+    const RT_GLOBAL PackedNode* nodes;
     const RT_GLOBAL TriRec* tris;
     BoxRay br;
     RayPrep rp;
 };
 
-RT_DEV float tlas_bound_of(const SceneView& sc) { return ((const RT_GLOBAL BvhNode*) sc.tlas_nodes)[0].bound; }
-
 RT_DEV void trace_top_level(const SceneView& sc, f3 o, f3 d, TraceState& S) {
     S.bottom = false;
-    S.nodes = (const RT_GLOBAL BvhNode*) sc.tlas_nodes;
-    S.br = make_box_ray(o, d, tlas_bound_of(sc));
+    S.nodes = (const RT_GLOBAL PackedNode*) sc.tlas_nodes;
+    S.br = make_box_ray(o, d, sc.tlas_bound, mk3(sc.tlas_ctr[0], sc.tlas_ctr[1], sc.tlas_ctr[2]),
+                        mk3(sc.tlas_inv_h[0], sc.tlas_inv_h[1], sc.tlas_inv_h[2]));
 }
 
 // DXR semantics: inside an instance the ray is in object space and t is preserved
 RT_DEV void trace_bottom_level(const SceneView& sc, f3 o, f3 d, TraceState& S) {
     const RT_GLOBAL InstRec* in = (const RT_GLOBAL InstRec*) sc.insts + S.cur_inst;
-    Quad m0 = ldq(in, 0), m1 = ldq(in, 1), m2 = ldq(in, 2), m3 = ldq(in, 3);
+    Quad m0 = ldq(in, 0), m1 = ldq(in, 1), m2 = ldq(in, 2), m3 = ldq(in, 3), m4 = ldq(in, 4), m5 = ldq(in, 5);
     float w2o[12] = { m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w };
     f3 oo = xform_point43(w2o, o);
     f3 od = xform_dir43(w2o, d);
     S.rp = prepare_ray(oo, od);
     unsigned long long pn = ((unsigned long long) as_u32(m3.y) << 32) | as_u32(m3.x);
-    S.nodes = (const RT_GLOBAL BvhNode*) pn; S.tris = (const RT_GLOBAL TriRec*) (pn + as_u32(m3.z));
-    S.br = make_box_ray(oo, od, m3.w);
+    S.nodes = (const RT_GLOBAL PackedNode*) pn; S.tris = (const RT_GLOBAL TriRec*) (pn + as_u32(m3.z));
+    S.br = make_box_ray(oo, od, m3.w, mk3(m4.x, m4.y, m4.z), mk3(m4.w, m5.x, m5.y));
     S.bottom = true;
 }
 
@@ -189,16 +210,23 @@ RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, S
     for (;;) {
         // ---- inner nodes ---------------------------------------------------------------------------------------
         while (S.cur >= 0) {
-            const RT_GLOBAL BvhNode* n = S.nodes + S.cur;
-            Quad q0 = ldq(n, 0), q1 = ldq(n, 1), q2 = ldq(n, 2), q3 = ldq(n, 3);
+            const RT_GLOBAL PackedNode* n = S.nodes + S.cur;
+            const Quad q0 = ldq(n, 0), q1 = ldq(n, 1);
             const int top = st.top();
             if (COUNT) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; }
-            float lo0[3] = { q0.x, q0.y, q0.z }, hi0[3] = { q0.w, q1.x, q1.y };
-            float lo1[3] = { q1.z, q1.w, q2.x }, hi1[3] = { q2.y, q2.z, q2.w };
-            float e0, e1;
-            const bool h0 = box_test(S.br, lo0, hi0, tmin, S.best.t, e0);
-            const bool h1 = box_test(S.br, lo1, hi1, tmin, S.best.t, e1);
-            const int c0 = (int) as_u32(q3.x), c1 = (int) as_u32(q3.y);
+            const BoxRay& r = S.br;
+            // entry / exit planes of both children, one packed word per axis
+            const u32 nwx = as_u32(r.px ? q0.x : q0.y), fwx = as_u32(r.px ? q0.y : q0.x);
+            const u32 nwy = as_u32(r.py ? q0.z : q0.w), fwy = as_u32(r.py ? q0.w : q0.z);
+            const u32 nwz = as_u32(r.pz ? q1.x : q1.y), fwz = as_u32(r.pz ? q1.y : q1.x);
+            const float e0 = fmaxf(fmaxf(__builtin_fmaf(half_lo(nwx), r.idx, r.cnx), __builtin_fmaf(half_lo(nwy), r.idy, r.cny)), __builtin_fmaf(half_lo(nwz), r.idz, r.cnz));
+            const float x0 = fminf(fminf(__builtin_fmaf(half_lo(fwx), r.idx, r.cfx), __builtin_fmaf(half_lo(fwy), r.idy, r.cfy)), __builtin_fmaf(half_lo(fwz), r.idz, r.cfz));
+            const float e1 = fmaxf(fmaxf(__builtin_fmaf(half_hi(nwx), r.idx, r.cnx), __builtin_fmaf(half_hi(nwy), r.idy, r.cny)), __builtin_fmaf(half_hi(nwz), r.idz, r.cnz));
+            const float x1 = fminf(fminf(__builtin_fmaf(half_hi(fwx), r.idx, r.cfx), __builtin_fmaf(half_hi(fwy), r.idy, r.cfy)), __builtin_fmaf(half_hi(fwz), r.idz, r.cfz));
+            // hit iff the padded slab intervals and [tmin, best t] have a common point
+            const bool h0 = fmaxf(e0, tmin) <= fminf(x0, S.best.t);
+            const bool h1 = fmaxf(e1, tmin) <= fminf(x1, S.best.t);
+            const int c0 = (int) as_u32(q1.z), c1 = (int) as_u32(q1.w);
             const bool both = h0 && h1, any = h0 || h1, first0 = e0 <= e1;
             st.put(first0 ? c1 : c0, both);       // the far child, kept only when both boxes are hit
             int next = h0 ? c0 : c1;              // the only child hit ...

@@ -43,6 +43,8 @@ struct LbvhWorkspace {
     float* cost = nullptr;
     u32* collapsed = nullptr;
     void* sort_scratch = nullptr;
+    rtd::BvhNode* tree_nodes = nullptr; // the tree as the builders write it (64-byte nodes), packed afterwards
+    rtd::TreeInfo* tree_info = nullptr;
     u32 capacity = 0;
 };
 int lbvh_workspace_reserve(LbvhWorkspace& w, u32 n);
@@ -82,7 +84,8 @@ int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const rtd::InstShade* s
 // PLOC for the top level, 4 = both PLOC and SAH, keeping the tree with the lower surface-area cost
 // sah_tri: cost of one triangle test relative to one two-child node step in the surface-area heuristic
 static constexpr u32 SAH_BUILD_MAX = 1u << 18;
-int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace* sw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, rtd::BvhNode* nodes_out, u32* perm_out);
+// builds into w.tree_nodes, packs the tree into nodes_out (max(n - 1, 1) nodes) and leaves its TreeInfo in w.tree_info
+int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace* sw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, rtd::PackedNode* nodes_out, u32* perm_out);
 // TriRec array in leaf order
 int lbvh_write_trirecs(hipStream_t s, const u32* perm, const RtVertex* verts, const uint16_t* indices,
                        const u32* tri_geometry, const rtd::GeomRec* geoms, u32 n_tris, rtd::TriRec* out);
