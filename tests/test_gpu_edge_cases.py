@@ -152,6 +152,26 @@ def test_single_triangle_meshes_and_mirrored_transforms(oracle_mod):
     _check(s, oracle_mod, frames=2)
 
 
+def test_far_from_the_origin_and_offset_meshes(oracle_mod):
+    """the whole scene and the camera moved to (3000, -2000, 1500), one mesh stored 500 units away from its object-space
+    origin and brought back by its instance transform: the box test runs in each tree's own frame with planes rounded
+    to half floats, and its padding scales with the coordinates; no hit may be lost to either"""
+    s = scenes.debug_cube(72, 56, spp=2, bounces=3)
+    shift = np.array([3000.0, -2000.0, 1500.0], dtype=np.float32)
+    geos = s.blas[0]
+    moved = geos[0]["vertices"].copy()
+    moved["position"] += np.float32(500.0)
+    s.blas[0] = [scenes._geo(moved, geos[0]["indices"], geos[0]["shader"], geos[0]["color"])]
+    m0, b0 = s.instances[0]
+    m0 = m0.copy(); m0[3, :3] -= (np.float32(500.0) * (m0[0, :3] + m0[1, :3] + m0[2, :3]))  # p' = (p + 500) M -> p M
+    s.instances[0] = (m0, b0)
+    s.instances = [(np.concatenate([m[:3], (m[3:] + np.append(shift, np.float32(0.0))).astype(np.float32)]).astype(np.float32), b) for m, b in s.instances]
+    for k in range(3):
+        s.globals.camera_to_world[12 + k] += float(shift[k])
+    rays, hits = _check(s, oracle_mod, frames=2)
+    assert (hits["instance"] == 0).sum() > 200 and (hits["instance"] == 1).sum() > 200
+
+
 def test_status_codes_instead_of_abort():
     """prelude.h:185 aborts; the C-ABI returns a status and a message and stays usable"""
     from raytracer_amd import api
