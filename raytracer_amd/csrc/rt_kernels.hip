@@ -20,8 +20,9 @@ namespace rti {
 using namespace rtd;
 
 static constexpr int TRAVERSE_WAVE   = 64;
-static constexpr int LDS_STACK_DEPTH = 31;  // entries per lane kept in LDS; row 31 of the 8 KB per wave (20 waves/CU = the VGPR limit) is a dump row
-static constexpr int OVF_STACK_DEPTH = 32;  // global spill; 63 entries with the sentinel; the host checks tlas_depth + 1 + blas_depth <= 64
+static constexpr int LDS_STACK_DEPTH = 22;  // entries per lane kept in LDS (rows 0-21 of the 8 KB per wave: 20 waves/CU = the VGPR limit);
+static constexpr int LDS_SIDE_ROW    = 23;  // row 22 is a dump row, rows 23-31 hold the top-level box-test constants while a ray is inside an instance
+static constexpr int OVF_STACK_DEPTH = 42;  // global spill; 64 entries with the sentinel; the host checks tlas_depth + 1 + blas_depth <= 64
 static constexpr int BT = 256;
 static constexpr int SEG = 1024;            // rays per queue segment = threads per raygen / shade workgroup
 
@@ -46,6 +47,8 @@ struct LaneStack {
         lds[(i < LDS_STACK_DEPTH ? i : LDS_STACK_DEPTH) * TRAVERSE_WAVE] = v;
         if (i >= LDS_STACK_DEPTH && keep && i < LDS_STACK_DEPTH + OVF_STACK_DEPTH) spill[(size_t) (i - LDS_STACK_DEPTH) * spill_stride] = v;
     }
+    RT_DEV void save_side(const float* v) { for (int k = 0; k < 9; k++) ((RT_LDS float*) lds)[(LDS_SIDE_ROW + k) * TRAVERSE_WAVE] = v[k]; }
+    RT_DEV void load_side(float* v) const { for (int k = 0; k < 9; k++) v[k] = ((const RT_LDS float*) lds)[(LDS_SIDE_ROW + k) * TRAVERSE_WAVE]; }
     RT_DEV void push(int v) { put(v, true); sp++; }
     RT_DEV int pop() { int v = top(); sp--; return v; }
 };
@@ -208,7 +211,7 @@ RT_DEV void traverse_counters_flush(const PassArgs& a, const TraverseCounters& c
 // PRIMARY: bounce 0 of the camera pass; lane t traces the primary ray of thread_pixel(t), the hit goes to slot t.
 template <bool COUNT, int WAVES_PER_SIMD, bool PRIMARY>
 __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq, u32 sample_index) {
-    __shared__ int smem[(LDS_STACK_DEPTH + 1) * TRAVERSE_WAVE];
+    __shared__ int smem[32 * TRAVERSE_WAVE];
     const u32 qi = blockIdx.x * TRAVERSE_WAVE + threadIdx.x;
     bool active;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
