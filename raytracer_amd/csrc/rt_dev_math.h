@@ -148,17 +148,20 @@ struct RayPrep {
 RT_DEV RayPrep prepare_ray(f3 o, f3 d) {
     RayPrep r;
     r.o = o;
-    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    int kz = 0; float am = ax;
-    if (ay > am) { kz = 1; am = ay; }
-    if (az > am) { kz = 2; }
-    int kx = kz + 1; if (kx == 3) kx = 0;
-    int ky = kx + 1; if (ky == 3) ky = 0;
-    float dz = comp3(d, kz);
-    if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
-    r.kx = kx; r.ky = ky; r.kz = kz;
-    r.sx = comp3(d, kx) / dz;
-    r.sy = comp3(d, ky) / dz;
+    // kz = the axis of the largest |d| (the first one on ties), kx = kz + 1, ky = kz + 2 (mod 3), kx and ky exchanged
+    // when d[kz] < 0 (keeps the winding); written as selects on two comparisons
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    const bool y_over_x = ay > ax;
+    const bool z_over = az > (y_over_x ? ay : ax);
+    const int kz = z_over ? 2 : (y_over_x ? 1 : 0);
+    const float dz = z_over ? d.z : (y_over_x ? d.y : d.x);
+    const float d1 = z_over ? d.x : (y_over_x ? d.z : d.y); // d[kz + 1]
+    const float d2 = z_over ? d.y : (y_over_x ? d.x : d.z); // d[kz + 2]
+    const int k1 = z_over ? 0 : (y_over_x ? 2 : 1), k2 = z_over ? 1 : (y_over_x ? 0 : 2);
+    const bool flip = dz < 0.0f;
+    r.kx = flip ? k2 : k1; r.ky = flip ? k1 : k2; r.kz = kz;
+    r.sx = (flip ? d2 : d1) / dz;
+    r.sy = (flip ? d1 : d2) / dz;
     r.sz = 1.0f / dz;
     return r;
 }
