@@ -151,6 +151,7 @@ void free_sample_points(rt_ctx* c) {
 void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     memset(&a, 0, sizeof a);
     a.g = c->g;
+    for (int k = 0; k < 3; k++) a.camera_origin[k] = c->g.camera_to_world[12 + k] / c->g.camera_to_world[15];
     a.fudge = (c->flags & RT_FLAG_ENABLE_SSS) ? c->g.translucent_bssrdf_fudge : 0.0f;
     a.width = c->width; a.height = c->height;
     a.tile_rank = c->tile_rank; a.tile_world = c->tile_world;

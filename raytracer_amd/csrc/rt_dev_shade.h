@@ -116,9 +116,11 @@ RT_DEV void shade_ray(const ShadeScene& sc, const RtGlobals& g, float fudge, f3 
 }
 
 // camera ray for pixel (px, py), raytracing.hlsl:141-149; draws two random11 (x first, Q6)
-RT_DEV void camera_ray(const RtGlobals& g, u32 px, u32 py, u32 width, u32 height, u32& rng, f3& origin, f3& direction) {
+// `camera_origin` = camera_to_world[3].xyz / camera_to_world[3].w: the same for every pixel, so the host divides
+// (IEEE division, same quotient) instead of every lane
+RT_DEV void camera_ray(const RtGlobals& g, const float* camera_origin, u32 px, u32 py, u32 width, u32 height, u32& rng, f3& origin, f3& direction) {
     const float* m = g.camera_to_world;
-    origin = mk3(m[12], m[13], m[14]) / m[15];
+    origin = mk3(camera_origin[0], camera_origin[1], camera_origin[2]);
     float dx = (float) px + 0.5f, dy = (float) py + 0.5f;
     float jx = random11(rng);
     float jy = random11(rng);

@@ -122,6 +122,7 @@ struct DeviceStats { // lives in device memory
 
 struct PassArgs {
     RtGlobals g;
+    float camera_origin[3];      // camera_to_world[3].xyz / camera_to_world[3].w (raytracing.hlsl:143), divided once on the host
     float fudge;                 // translucent_bssrdf_fudge or 0 when SSS is disabled (raytracing.cpp:653-657)
     u32 width, height;
     u32 tile_rank, tile_world, tiles_x, tiles_y, n_local_tiles;
