@@ -435,9 +435,11 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
         for (int t = threadIdx.x; t < a.bssrdf_texels; t += GATHER_BLOCK)
             s_tab[t] = make_float4(a.bssrdf_table[3 * t], a.bssrdf_table[3 * t + 1], a.bssrdf_table[3 * t + 2], 0.0f);
     // radiance-only arithmetic (covered by the 1e-4 tolerance): fudge / scale^2 is folded into one
-    // factor, and the dipole uses the hardware sqrt / rcp / exp2.  The table coordinate radius / scale stays IEEE: near
-    // the end of the profile's support the texels are ~1e-7 and an ulp of the coordinate is a visible relative error.
+    // factor, and the dipole uses the hardware sqrt / rcp / exp2.  The table coordinate radius / scale stays (all but)
+    // correctly rounded -- near the end of the profile's support the texels are ~1e-7 and an ulp of the coordinate is a
+    // visible relative error -- but by refinement steps (sqrt_refined, div_by_shared) instead of the library sequences.
     const float fudge_over_z = a.fudge / (scale * scale);
+    const float inv_scale = 1.0f / scale;
     const float eta = a.g.translucent_refractive_index;
     DipoleConst cr = dipole_constants(a.g.translucent_scattering[0], a.g.translucent_absorption[0], eta);
     DipoleConst cg = dipole_constants(a.g.translucent_scattering[1], a.g.translucent_absorption[1], eta);
@@ -476,11 +478,12 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
             auto term = [&](u32 k) -> f3 {
                 const GatherPoint gp = s_pts[k];
                 f3 dp = mk3(gp.px, gp.py, gp.pz) - hit;
-                float radius = MODE != 0 ? sqrtf(dot3(dp, dp)) : fast_sqrt(dot3(dp, dp));
+                float radius = MODE != 0 ? sqrt_refined(dot3(dp, dp)) : fast_sqrt(dot3(dp, dp));
                 f3 bs;
                 if (MODE != 0) {
-                    f3 tv = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, radius / scale)
-                                      : sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, radius / scale);
+                    const float coord = div_by_shared(radius, scale, inv_scale);
+                    f3 tv = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, coord)
+                                      : sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, coord);
                     bs = fudge_over_z * tv;                                                                  // :272-276
                 } else if (grey) { float v = dipole_eval_fast(cr, radius); bs = mk3(v, v, v); }               // :278-301
                 else bs = mk3(dipole_eval_fast(cr, radius), dipole_eval_fast(cg, radius), dipole_eval_fast(cb, radius));
@@ -574,6 +577,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather_hg(PassArgs a) {
     const float4* pay = a.hg.pay + sl.offset;
     const float scale = a.g.translucent_bssrdf_scale;
     const float fudge_over_z = a.fudge / (scale * scale); // as in k_gather
+    const float inv_scale = 1.0f / scale;
     const float eta = a.g.translucent_refractive_index;
     DipoleConst cr = dipole_constants(a.g.translucent_scattering[0], a.g.translucent_absorption[0], eta);
     DipoleConst cg = dipole_constants(a.g.translucent_scattering[1], a.g.translucent_absorption[1], eta);
@@ -583,8 +587,9 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather_hg(PassArgs a) {
                       a.g.translucent_absorption[0] == a.g.translucent_absorption[1] && a.g.translucent_absorption[0] == a.g.translucent_absorption[2];
     auto bssrdf = [&](float radius) -> f3 {
         if (MODE != 0) {
-            f3 tv = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, radius / scale)
-                              : sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, radius / scale);
+            const float coord = div_by_shared(radius, scale, inv_scale);
+            f3 tv = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, coord)
+                              : sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, coord);
             return fudge_over_z * tv;
         }
         if (grey) { float v = dipole_eval_fast(cr, radius); return mk3(v, v, v); }
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather_hg(PassArgs a) {
             for (u32 k = 0; k < n.count; k++) {
                 const float4 p = pos[n.first + k], w = pay[n.first + k];
                 f3 dp = mk3(p.x, p.y, p.z) - hit;
-                E = E + bssrdf(MODE != 0 ? sqrtf(dot3(dp, dp)) : fast_sqrt(dot3(dp, dp))) * mk3(w.x, w.y, w.z);
+                E = E + bssrdf(MODE != 0 ? sqrt_refined(dot3(dp, dp)) : fast_sqrt(dot3(dp, dp))) * mk3(w.x, w.y, w.z);
             }
             terms += n.count;
             continue;
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather_hg(PassArgs a) {
         float d2 = dot3(d, d);
         if (d2 > n.radius2 && (float) n.count * sl.mean_area < a.hg.max_solid_angle * d2) {
             const float4 w = sums[id];
-            E = E + bssrdf(MODE != 0 ? sqrtf(d2) : fast_sqrt(d2)) * mk3(w.x, w.y, w.z);
+            E = E + bssrdf(MODE != 0 ? sqrt_refined(d2) : fast_sqrt(d2)) * mk3(w.x, w.y, w.z);
             terms += 1u;
         } else if (sp + 2 <= HG_STACK) {
             stack[(sp++) * GATHER_BLOCK] = n.right;
