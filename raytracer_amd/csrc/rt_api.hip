@@ -80,7 +80,8 @@ struct rt_ctx {
     u32 tile_rank = 0, tile_world = 1;
     // path buffers
     u32 n_paths = 0; float* d_arena = nullptr;
-    RayQueue q[2]; HitBuf hits; PathState ps; GatherQueue gq; int* d_stack_spill = nullptr;
+    RayQueue q[2]; HitBuf hits; PathState ps; SlotState st[2]; GatherQueue gq; int* d_stack_spill = nullptr;
+    int ray_sort = 1; // RT_RAY_SORT: group the surviving rays of a bounce by direction octant (fused camera pass)
     u32* d_seg_count = nullptr; u32 n_segments_cap = 0; DeviceStats* d_stats = nullptr;
     // BSSRDF tables
     float* d_table[2] = { nullptr, nullptr }; int table_texels[2] = { 0, 0 }; int profile = 0;
@@ -88,7 +89,7 @@ struct rt_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, timed_gather; double traverse_ms = 0, gather_ms = 0;
     uint64_t traverse_launches = 0, gather_launches = 0, primary_rays = 0;
     double blas_build_ms = 0, tlas_build_ms = 0; uint64_t blas_triangles = 0;
-    rt_ctx() { memset(&g, 0, sizeof g); memset(q, 0, sizeof q); memset(&hits, 0, sizeof hits); memset(&ps, 0, sizeof ps); memset(&gq, 0, sizeof gq); }
+    rt_ctx() { memset(&g, 0, sizeof g); memset(q, 0, sizeof q); memset(&hits, 0, sizeof hits); memset(&ps, 0, sizeof ps); memset(st, 0, sizeof st); memset(&gq, 0, sizeof gq); }
 };
 
 namespace {
@@ -118,7 +119,7 @@ int ensure_path_buffers(rt_ctx* c) {
     RT_HIP(hipMalloc(&c->d_seg_count, sizeof(u32) * (4 * (size_t) segs + 1))); // 2 queues, gather, gather offsets
     RT_HIP(hipMemset(c->d_seg_count, 0, sizeof(u32) * (4 * (size_t) segs + 1)));
     c->n_segments_cap = segs;
-    const int n_arrays = 14 /* 2 queues x (6 + path) */ + 5 /* hits */ + 15 /* path state */ + 9 /* gather */ + 42 /* stack spill */;
+    const int n_arrays = 14 /* 2 queues x (6 + path) */ + 5 /* hits */ + 15 /* path state */ + 14 /* slot state x 2 */ + 9 /* gather */ + 42 /* stack spill */;
     size_t stride = ((size_t) need + 63) & ~(size_t) 63;
     RT_HIP(hipMalloc(&c->d_arena, stride * 4 * n_arrays));
     float* p = c->d_arena;
@@ -133,6 +134,10 @@ int ensure_path_buffers(rt_ctx* c) {
     c->ps.rad_x = take(); c->ps.rad_y = take(); c->ps.rad_z = take(); c->ps.alpha = take();
     c->ps.fd_x = take(); c->ps.fd_y = take(); c->ps.fd_z = take();
     c->ps.sum_x = take(); c->ps.sum_y = take(); c->ps.sum_z = take(); c->ps.sum_a = take();
+    for (int k = 0; k < 2; k++) {
+        c->st[k].rng = (u32*) take(); c->st[k].thr_x = take(); c->st[k].thr_y = take(); c->st[k].thr_z = take();
+        c->st[k].rad_x = take(); c->st[k].rad_y = take(); c->st[k].rad_z = take();
+    }
     c->gq.path = (u32*) take(); c->gq.hx = take(); c->gq.hy = take(); c->gq.hz = take(); c->gq.tf = take();
     c->gq.kx = take(); c->gq.ky = take(); c->gq.kz = take(); c->gq.ti = (int*) take();
     c->d_stack_spill = (int*) p; p += 42 * stride;
@@ -151,6 +156,8 @@ void free_sample_points(rt_ctx* c) {
 void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     memset(&a, 0, sizeof a);
     a.g = c->g;
+    a.ray_sort = c->ray_sort ? 1u : 0u;
+    a.st[0] = c->st[0]; a.st[1] = c->st[1];
     for (int k = 0; k < 3; k++) a.camera_origin[k] = c->g.camera_to_world[12 + k] / c->g.camera_to_world[15];
     a.fudge = (c->flags & RT_FLAG_ENABLE_SSS) ? c->g.translucent_bssrdf_fudge : 0.0f;
     a.width = c->width; a.height = c->height;
@@ -312,6 +319,7 @@ int rt_create(const int* devices, int n, rt_ctx** out) {
     c->device = devices[0];
     if (const char* v = getenv("RT_BVH_BUILDER")) c->bvh_builder = atoi(v);
     if (const char* v = getenv("RT_SAH_TRI")) c->sah_tri = (float) atof(v);
+    if (const char* v = getenv("RT_RAY_SORT")) c->ray_sort = atoi(v);
     if (const char* v = getenv("RT_EXACT_INSTANCE_BOXES")) c->exact_instance_boxes = atoi(v) != 0;
     RT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;

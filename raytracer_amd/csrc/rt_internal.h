@@ -100,6 +100,9 @@ struct PathState {
     float *fd_x, *fd_y, *fd_z;           // probe pass: direction after trace_path_sample (raytracing.hlsl:258)
     float *sum_x, *sum_y, *sum_z, *sum_a; // per-dispatch sample sum
 };
+// state of a path in flight that travels with its ray (slot-indexed, ping-pong like the queues): used by the fused camera
+// pass, where k_shade groups the surviving rays by direction octant, so that reads and writes stay coalesced
+struct SlotState { u32* rng; float *thr_x, *thr_y, *thr_z, *rad_x, *rad_y, *rad_z; };
 struct GatherQueue { u32* path; float *hx, *hy, *hz, *tf, *kx, *ky, *kz; int* ti; };
 
 // hierarchical gather (rt_set_gather_mode): per-instance tree over the sample points, DESIGN.md section 8
@@ -123,6 +126,8 @@ struct DeviceStats { // lives in device memory
 struct PassArgs {
     RtGlobals g;
     float camera_origin[3];      // camera_to_world[3].xyz / camera_to_world[3].w (raytracing.hlsl:143), divided once on the host
+    u32 ray_sort;                // fused camera pass: survivors of a bounce are grouped by direction octant inside their segment (RT_RAY_SORT)
+    SlotState st[2];             // fused camera pass: path state by queue slot
     float fudge;                 // translucent_bssrdf_fudge or 0 when SSS is disabled (raytracing.cpp:653-657)
     u32 width, height;
     u32 tile_rank, tile_world, tiles_x, tiles_y, n_local_tiles;
