@@ -277,7 +277,7 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
 // FUSED: a path that ends here also finishes its pixel (sample sum, accumulate, tone-map) -- no resolve kernel, and no
 // radiance / alpha / sum traffic for finished paths.  Not usable while the gather kernel may add emission afterwards.
 template <bool PRIMARY, bool FUSED>
-__global__ __launch_bounds__(SEG) void k_shade(PassArgs a, u32 inq, u32 bounce, u32 sample_index) {
+__global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounce, u32 sample_index) { // 8 waves per SIMD = two workgroups per CU: at most 64 VGPRs
     __shared__ u32 s_wave[SEG / 64];
     const u32 qi = blockIdx.x * SEG + threadIdx.x;
     bool active, cont = false, gather = false;
