@@ -81,6 +81,7 @@ struct rt_ctx {
     // path buffers
     u32 n_paths = 0; float* d_arena = nullptr;
     RayQueue q[2]; HitBuf hits; PathState ps; SlotState st[2]; GatherQueue gq; int* d_stack_spill = nullptr;
+    u32* d_task_counter = nullptr; u32 persistent_slots = 0; int persistent = -1; // RT_PERSISTENT: -1 by scene (default), 0 never, bit 0 queued launches, bit 1 primary launches
     int ray_sort = 1; // RT_RAY_SORT: group the surviving rays of a bounce by direction octant (fused camera pass)
     u32* d_seg_count = nullptr; u32 n_segments_cap = 0; DeviceStats* d_stats = nullptr;
     // BSSRDF tables
@@ -157,6 +158,10 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     memset(&a, 0, sizeof a);
     a.g = c->g;
     a.ray_sort = c->ray_sort ? 1u : 0u;
+    a.task_counter = c->d_task_counter; a.persistent_slots = c->persistent_slots;
+    // persistent traversal waves pay ~2.5 us per 64-ray task and win back the dispatcher's idle slots: worth it when tasks
+    // are long, i.e. when rays walk a deep top level before they reach a mesh (k_traverse, rt_kernels.hip)
+    a.persistent = c->persistent >= 0 ? (u32) c->persistent : (c->n_instances >= 1024u ? 1u : 0u);
     a.st[0] = c->st[0]; a.st[1] = c->st[1];
     for (int k = 0; k < 3; k++) a.camera_origin[k] = c->g.camera_to_world[12 + k] / c->g.camera_to_world[15];
     a.fudge = (c->flags & RT_FLAG_ENABLE_SSS) ? c->g.translucent_bssrdf_fudge : 0.0f;
@@ -320,6 +325,14 @@ int rt_create(const int* devices, int n, rt_ctx** out) {
     if (const char* v = getenv("RT_BVH_BUILDER")) c->bvh_builder = atoi(v);
     if (const char* v = getenv("RT_SAH_TRI")) c->sah_tri = (float) atof(v);
     if (const char* v = getenv("RT_RAY_SORT")) c->ray_sort = atoi(v);
+    if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
+    {
+        hipDeviceProp_t prop;
+        RT_HIP(hipGetDeviceProperties(&prop, c->device));
+        c->persistent_slots = (u32) prop.multiProcessorCount * 4u * 5u;
+        RT_HIP(hipMalloc(&c->d_task_counter, 65 * 128));
+        RT_HIP(hipMemset(c->d_task_counter, 0, 65 * 128));
+    }
     if (const char* v = getenv("RT_EXACT_INSTANCE_BOXES")) c->exact_instance_boxes = atoi(v) != 0;
     RT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -341,6 +354,7 @@ void rt_destroy(rt_ctx* c) {
     for (auto& m : c->translucent_meshes) dev_free(m.d_partial_areas);
     free_sample_points(c);
     dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
+    dev_free(c->d_task_counter);
     dev_free(c->d_accumulator); dev_free(c->d_render_target); dev_free(c->d_capture); dev_free(c->d_arena);
     dev_free(c->d_seg_count); dev_free(c->d_stats); dev_free(c->d_table[0]); dev_free(c->d_table[1]);
     lbvh_workspace_free(c->lbvh); ploc_workspace_free(c->ploc); sah_workspace_free(c->sah);

@@ -126,6 +126,9 @@ struct DeviceStats { // lives in device memory
 struct PassArgs {
     RtGlobals g;
     float camera_origin[3];      // camera_to_world[3].xyz / camera_to_world[3].w (raytracing.hlsl:143), divided once on the host
+    u32* task_counter;           // persistent traversal: 64 task counters + 1 done counter, 128 bytes apart; all zero between launches
+    u32 persistent_slots;        // wave slots of the device for the traversal kernel (CUs x 4 SIMDs x 5 waves), 0 = never persistent
+    u32 persistent;              // bit 0: queued (secondary / probe) launches persistent, bit 1: primary launches too
     u32 ray_sort;                // fused camera pass: survivors of a bounce are grouped by direction octant inside their segment (RT_RAY_SORT)
     SlotState st[2];             // fused camera pass: path state by queue slot
     float fudge;                 // translucent_bssrdf_fudge or 0 when SSS is disabled (raytracing.cpp:653-657)

@@ -233,43 +233,95 @@ RT_DEV void traverse_counters_flush(const PassArgs& a, const TraverseCounters& c
 }
 
 // PRIMARY: bounce 0 of the camera pass; lane t traces the primary ray of thread_pixel(t), the hit goes to slot t.
-template <bool COUNT, int WAVES_PER_SIMD, bool PRIMARY>
-__global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq, u32 sample_index) {
+// PERSISTENT: the launch has one workgroup per wave slot of the GPU; a wave that has finished its 64 rays takes the next
+// 64 from a global counter instead of ending.  The workgroup dispatcher keeps only ~80 % of the slots occupied when it
+// has to place tens of thousands of one-wave workgroups whose lifetimes range from 4 us (the empty waves behind the
+// compacted part of a segment) to ~90 us (timeline from per-wave timestamps); persistent waves
+// keep 90 % occupied and balance the end of the launch by themselves.  The price is one device-scope atomic round trip
+// per task (~2.5 us under load, exposed: memory operations return in order), so this pays when tasks are long: +24 %
+// on the 52,743-instance field (tasks of ~100 us), -10 % on the bunny (24 us), -34 % on the Cornell box (5 us).
+// rt_api.hip picks the mode per scene.
+// The tasks (waves of 64 queue slots) are dealt to TASK_PARTS interleaved partitions, each with its own counter in its
+// own cache line: atomics on ONE address run at ~90 per microsecond on MI355X, which would make the 32,640 tasks of a
+// 1080p launch cost 0.36 ms.  A wave works through its home partition, then moves to the one with the most tasks left.
+static constexpr u32 TASK_PARTS = 64, TASK_STRIDE = 32; // counters 128 bytes apart; counter TASK_PARTS counts the waves that are done
+template <bool COUNT, int WAVES_PER_SIMD, bool PRIMARY, bool PERSISTENT>
+__global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq, u32 sample_index, u32 n_tasks) {
     __shared__ int smem[32 * TRAVERSE_WAVE];
-    const u32 qi = blockIdx.x * TRAVERSE_WAVE + threadIdx.x;
-    bool active;
-    f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
-    if (PRIMARY) {
-        u32 px, py;
-        active = thread_pixel(a, qi, px, py);
-        if (active) { u32 rng; primary_ray(a, px, py, py * a.width + px, sample_index, rng, o, d); }
-    } else {
-        const u32 seg = blockIdx.x / (SEG / TRAVERSE_WAVE);
-        const u32 idx = (blockIdx.x % (SEG / TRAVERSE_WAVE)) * TRAVERSE_WAVE + threadIdx.x;
-        if (blockIdx.x == 0) { // ray statistics: one wave sums the segment counts of this launch
-            u32 sum = 0;
-            for (u32 k = threadIdx.x; k < a.n_segments; k += TRAVERSE_WAVE) sum += a.seg_count[inq][k];
-            sum = wave_sum(sum);
-            if (threadIdx.x == 0) atomicAdd(a.probe ? &a.stats->rays_probe : &a.stats->rays_camera, (unsigned long long) sum);
-        }
-        active = idx < a.seg_count[inq][seg];
-        if (active) {
-            const RayQueue& q = a.q[inq];
-            o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
-            d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
-        }
-    }
     TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
-    if (active) {
-        LaneStack st; st.lds = (RT_LDS int*) &smem[threadIdx.x]; st.spill = (RT_GLOBAL int*) (a.stack_spill + qi);
-        st.spill_stride = a.n_paths; st.sp = 1;
-        TraceState S;
-        trace_begin(a.scene, o, d, a.tmax, S);
-        trace_run<LaneStack, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, S, cnt);
-        a.hits.t[qi] = S.best.t; a.hits.u[qi] = S.best.u; a.hits.v[qi] = S.best.v;
-        a.hits.inst[qi] = S.best.inst; a.hits.tri[qi] = S.best.tri;
+    u32 part = blockIdx.x % TASK_PARTS;
+    // next task of partition `p`, or n_tasks when it has none left (wave-uniform; costs one atomic round trip)
+    auto take = [&](u32 p) -> u32 {
+        u32 k = 0;
+        if (threadIdx.x == 0) k = atomicAdd(a.task_counter + p * TASK_STRIDE, 1u);
+        k = (u32) __builtin_amdgcn_readfirstlane((int) k);
+        const u32 t = k * TASK_PARTS + p; // interleaved: the partitions advance through the queue together, so the rays in flight stay neighbours
+        return t < n_tasks ? t : n_tasks;
+    };
+    // the home partition has run dry: move to the partition with the most tasks left (one 64-lane load of all counters,
+    // one atomic), or end when none has any.  The counters only grow, so a partition seen dry stays dry.
+    auto steal = [&]() -> u32 {
+        for (int tries = 0; tries < 8; tries++) {
+            const u32 p = threadIdx.x; // TASK_PARTS == the wave width
+            const u32 taken = __hip_atomic_load(a.task_counter + p * TASK_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 size = n_tasks > p ? (n_tasks - p + TASK_PARTS - 1u) / TASK_PARTS : 0u;
+            u32 left = size > taken ? size - taken : 0u;
+            u32 best = (left << 6) | p; // largest remainder, ties to the higher partition index
+            for (int off = 32; off >= 1; off >>= 1) { u32 o2 = __shfl_xor(best, off); best = o2 > best ? o2 : best; }
+            if ((best >> 6) == 0u) return n_tasks;
+            part = best & 63u;
+            const u32 t = take(part);
+            if (t < n_tasks) return t;
+        }
+        return n_tasks;
+    };
+    u32 task = blockIdx.x; // = the wave of 64 consecutive queue slots (or pixels of a tile) this wave works on
+    if (PERSISTENT) { task = take(part); if (task >= n_tasks) task = steal(); }
+    while (task < n_tasks) {
+        u32 next = 0;
+        if (PERSISTENT && threadIdx.x == 0) next = atomicAdd(a.task_counter + part * TASK_STRIDE, 1u); // asked for early: back before the rays are
+        const u32 qi = task * TRAVERSE_WAVE + threadIdx.x;
+        bool active;
+        f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
+        if (PRIMARY) {
+            u32 px, py;
+            active = thread_pixel(a, qi, px, py);
+            if (active) { u32 rng; primary_ray(a, px, py, py * a.width + px, sample_index, rng, o, d); }
+        } else {
+            const u32 seg = task / (SEG / TRAVERSE_WAVE);
+            const u32 idx = (task % (SEG / TRAVERSE_WAVE)) * TRAVERSE_WAVE + threadIdx.x;
+            if (task == 0) { // ray statistics: one wave sums the segment counts of this launch
+                u32 sum = 0;
+                for (u32 k = threadIdx.x; k < a.n_segments; k += TRAVERSE_WAVE) sum += a.seg_count[inq][k];
+                sum = wave_sum(sum);
+                if (threadIdx.x == 0) atomicAdd(a.probe ? &a.stats->rays_probe : &a.stats->rays_camera, (unsigned long long) sum);
+            }
+            active = idx < a.seg_count[inq][seg];
+            if (active) {
+                const RayQueue& q = a.q[inq];
+                o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
+                d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
+            }
+        }
+        if (PERSISTENT) next = (u32) __builtin_amdgcn_readfirstlane((int) next);
+        if (active) {
+            LaneStack st; st.lds = (RT_LDS int*) &smem[threadIdx.x]; st.spill = (RT_GLOBAL int*) (a.stack_spill + qi);
+            st.spill_stride = a.n_paths; st.sp = 1;
+            TraceState S;
+            trace_begin(a.scene, o, d, a.tmax, S);
+            trace_run<LaneStack, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, S, cnt);
+            a.hits.t[qi] = S.best.t; a.hits.u[qi] = S.best.u; a.hits.v[qi] = S.best.v;
+            a.hits.inst[qi] = S.best.inst; a.hits.tri[qi] = S.best.tri;
+        }
+        if (!PERSISTENT) break;
+        task = next * TASK_PARTS + part < n_tasks ? next * TASK_PARTS + part : n_tasks;
+        if (task >= n_tasks) task = steal();
     }
     if (COUNT) traverse_counters_flush(a, cnt);
+    if (PERSISTENT && threadIdx.x == 0) { // the last wave out leaves the counters at zero for the next launch
+        const u32 done = atomicAdd(a.task_counter + TASK_PARTS * TASK_STRIDE, 1u);
+        if (done == gridDim.x - 1u) for (u32 k = 0; k <= TASK_PARTS; k++) a.task_counter[k * TASK_STRIDE] = 0u;
+    }
 }
 
 // ---- hit / miss shaders + the tail of the trace_path_sample loop body (raytracing.hlsl:113-119) ------------------
@@ -715,13 +767,19 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
     size_t n = pass_paths(a);
     if (!n) return RT_OK;
     dim3 grid = blocks(n, TRAVERSE_WAVE), block(TRAVERSE_WAVE);
+    const u32 n_tasks = grid.x;
     // 5 waves per SIMD = 96 VGPRs = what the LDS stacks allow as well (8 KB per wave)
-    if (primary) {
-        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true>), grid, block, 0, s, a, in_queue, sample_index);
-        else hipLaunchKernelGGL((k_traverse<false, 5, true>), grid, block, 0, s, a, in_queue, sample_index);
+    const bool persistent = a.persistent_slots != 0 && !count_traversal && (primary ? (a.persistent & 2u) != 0 : (a.persistent & 1u) != 0) && n_tasks > a.persistent_slots;
+    if (persistent) {
+        dim3 pgrid(a.persistent_slots);
+        if (primary) hipLaunchKernelGGL((k_traverse<false, 5, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        else hipLaunchKernelGGL((k_traverse<false, 5, false, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
+    } else if (primary) {
+        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        else hipLaunchKernelGGL((k_traverse<false, 5, true, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
     } else {
-        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, false>), grid, block, 0, s, a, in_queue, sample_index);
-        else hipLaunchKernelGGL((k_traverse<false, 5, false>), grid, block, 0, s, a, in_queue, sample_index);
+        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        else hipLaunchKernelGGL((k_traverse<false, 5, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
     }
     RT_HIP(hipGetLastError());
     return RT_OK;

@@ -36,6 +36,18 @@ def test_c3_cornell_1080p_every_ray(oracle_mod):
     assert rays > 4500000   # hit records are tapped for sample 0 of the dispatch; the image covers both samples
 
 
+@pytest.mark.parametrize("mode", ["3", "0"])
+def test_persistent_and_dispatched_traversal_agree_with_the_oracle(oracle_mod, monkeypatch, mode):
+    """k_traverse has two ways of handing 64-ray tasks to waves: one workgroup per task (RT_PERSISTENT=0), or one
+    persistent wave per slot that takes tasks from partitioned counters with stealing (bit 0: queued launches, bit 1:
+    primary launches); the library picks by scene.  Both are forced here on a frame large enough for the persistent
+    grid (more than 5,120 tasks), with ray grouping on, and compared ray by ray; two frames, so that the counters are
+    seen to be left at zero by the first."""
+    monkeypatch.setenv("RT_PERSISTENT", mode)
+    rays = _full_parity(scenes.bunny(1280, 720, spp=1, bounces=2), oracle_mod, frames=2)
+    assert rays > 1200000
+
+
 def test_1080p_determinism_and_tile_split():
     from raytracer_amd import api, distributed
     scene = scenes.bunny(1920, 1080, spp=1, bounces=1)
