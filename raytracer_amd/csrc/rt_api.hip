@@ -82,6 +82,7 @@ struct rt_ctx {
     u32 n_paths = 0; float* d_arena = nullptr;
     RayQueue q[2]; HitBuf hits; PathState ps; SlotState st[2]; GatherQueue gq; int* d_stack_spill = nullptr;
     u32* d_task_counter = nullptr; u32 persistent_slots = 0; int persistent = -1; // RT_PERSISTENT: -1 by scene (default), 0 never, bit 0 queued launches, bit 1 primary launches
+    int wave_major = 1; // RT_WAVE_MAJOR
     int ray_sort = 1; // RT_RAY_SORT: group the surviving rays of a bounce by direction octant (fused camera pass)
     u32* d_seg_count = nullptr; u32 n_segments_cap = 0; DeviceStats* d_stats = nullptr;
     // BSSRDF tables
@@ -158,6 +159,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     memset(&a, 0, sizeof a);
     a.g = c->g;
     a.ray_sort = c->ray_sort ? 1u : 0u;
+    a.wave_major = c->wave_major ? 1u : 0u;
     a.task_counter = c->d_task_counter; a.persistent_slots = c->persistent_slots;
     // persistent traversal waves pay ~2.5 us per 64-ray task and win back the dispatcher's idle slots: worth it when tasks
     // are long, i.e. when rays walk a deep top level before they reach a mesh (k_traverse, rt_kernels.hip)
@@ -325,6 +327,7 @@ int rt_create(const int* devices, int n, rt_ctx** out) {
     if (const char* v = getenv("RT_BVH_BUILDER")) c->bvh_builder = atoi(v);
     if (const char* v = getenv("RT_SAH_TRI")) c->sah_tri = (float) atof(v);
     if (const char* v = getenv("RT_RAY_SORT")) c->ray_sort = atoi(v);
+    if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
     if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
     {
         hipDeviceProp_t prop;

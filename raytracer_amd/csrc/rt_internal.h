@@ -129,6 +129,7 @@ struct PassArgs {
     u32* task_counter;           // persistent traversal: 64 task counters + 1 done counter, 128 bytes apart; all zero between launches
     u32 persistent_slots;        // wave slots of the device for the traversal kernel (CUs x 4 SIMDs x 5 waves), 0 = never persistent
     u32 persistent;              // bit 0: queued (secondary / probe) launches persistent, bit 1: primary launches too
+    u32 wave_major;              // queued traverse launches: task -> (segment, wave) mapping, see k_traverse (RT_WAVE_MAJOR)
     u32 ray_sort;                // fused camera pass: survivors of a bounce are grouped by direction octant inside their segment (RT_RAY_SORT)
     SlotState st[2];             // fused camera pass: path state by queue slot
     float fudge;                 // translucent_bssrdf_fudge or 0 when SSS is disabled (raytracing.cpp:653-657)

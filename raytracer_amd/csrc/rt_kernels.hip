@@ -276,11 +276,12 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
         return n_tasks;
     };
     u32 task = blockIdx.x; // = the wave of 64 consecutive queue slots (or pixels of a tile) this wave works on
+
     if (PERSISTENT) { task = take(part); if (task >= n_tasks) task = steal(); }
     while (task < n_tasks) {
         u32 next = 0;
         if (PERSISTENT && threadIdx.x == 0) next = atomicAdd(a.task_counter + part * TASK_STRIDE, 1u); // asked for early: back before the rays are
-        const u32 qi = task * TRAVERSE_WAVE + threadIdx.x;
+        u32 qi = task * TRAVERSE_WAVE + threadIdx.x;
         bool active;
         f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
         if (PRIMARY) {
@@ -288,8 +289,13 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
             active = thread_pixel(a, qi, px, py);
             if (active) { u32 rng; primary_ray(a, px, py, py * a.width + px, sample_index, rng, o, d); }
         } else {
-            const u32 seg = task / (SEG / TRAVERSE_WAVE);
-            const u32 idx = (task % (SEG / TRAVERSE_WAVE)) * TRAVERSE_WAVE + threadIdx.x;
+            // queued launches take the waves of the segments "wave-major" (wave 0 of every segment, then wave 1, ...):
+            // segments are compacted, so the empty waves behind their fill all land at the end of the launch instead of
+            // taking dispatch slots between the working ones (C3, whose later bounces fill few waves per segment: +20 %)
+            const u32 seg = a.wave_major ? task % a.n_segments : task / (SEG / TRAVERSE_WAVE);
+            const u32 wis = a.wave_major ? task / a.n_segments : task % (SEG / TRAVERSE_WAVE);
+            const u32 idx = wis * TRAVERSE_WAVE + threadIdx.x;
+            qi = seg * SEG + idx;
             if (task == 0) { // ray statistics: one wave sums the segment counts of this launch
                 u32 sum = 0;
                 for (u32 k = threadIdx.x; k < a.n_segments; k += TRAVERSE_WAVE) sum += a.seg_count[inq][k];
