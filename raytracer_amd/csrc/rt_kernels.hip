@@ -595,27 +595,33 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
             }
             __syncthreads();
             if (!mine) continue;
-            // four points per trip: their sqrt / divide chains are independent and overlap; the sum stays in index order
-            auto term = [&](u32 k) -> f3 {
-                const GatherPoint gp = s_pts[k];
-                f3 dp = mk3(gp.px, gp.py, gp.pz) - hit;
-                float radius = MODE != 0 ? sqrt_refined(dot3(dp, dp)) : fast_sqrt(dot3(dp, dp));
-                f3 bs;
-                if (MODE != 0) {
-                    const float coord = div_by_shared(radius, scale, inv_scale);
-                    f3 tv = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, coord)
-                                      : sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, coord);
-                    bs = fudge_over_z * tv;                                                                  // :272-276
-                } else if (grey) { float v = dipole_eval_fast(cr, radius); bs = mk3(v, v, v); }               // :278-301
-                else bs = mk3(dipole_eval_fast(cr, radius), dipole_eval_fast(cg, radius), dipole_eval_fast(cb, radius));
-                return bs * mk3(gp.wx, gp.wy, gp.wz);
+            // four points per trip: their sqrt / divide chains are independent and overlap; the sum stays in index order.
+            // `GREY` is a compile-time flag of the loop (two copies): a branch on it between the four terms would keep
+            // the scheduler from interleaving their chains.
+            auto run = [&](auto grey_tag) {
+                constexpr bool GREY = decltype(grey_tag)::value;
+                auto term = [&](u32 k) -> f3 {
+                    const GatherPoint gp = s_pts[k];
+                    f3 dp = mk3(gp.px, gp.py, gp.pz) - hit;
+                    float radius = MODE != 0 ? sqrt_refined(dot3(dp, dp)) : fast_sqrt(dot3(dp, dp));
+                    f3 bs;
+                    if (MODE != 0) {
+                        const float coord = div_by_shared(radius, scale, inv_scale);
+                        f3 tv = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, coord)
+                                          : sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, coord);
+                        bs = fudge_over_z * tv;                                                                  // :272-276
+                    } else if (GREY) { float v = dipole_eval_fast(cr, radius); bs = mk3(v, v, v); }               // :278-301
+                    else bs = mk3(dipole_eval_fast(cr, radius), dipole_eval_fast(cg, radius), dipole_eval_fast(cb, radius));
+                    return bs * mk3(gp.wx, gp.wy, gp.wz);
+                };
+                u32 k = 0;
+                for (; k + 4 <= nk; k += 4) {
+                    f3 c0 = term(k), c1 = term(k + 1), c2 = term(k + 2), c3 = term(k + 3);
+                    E = E + c0; E = E + c1; E = E + c2; E = E + c3;
+                }
+                for (; k < nk; k++) E = E + term(k);
             };
-            u32 k = 0;
-            for (; k + 4 <= nk; k += 4) {
-                f3 c0 = term(k), c1 = term(k + 1), c2 = term(k + 2), c3 = term(k + 3);
-                E = E + c0; E = E + c1; E = E + c2; E = E + c3;
-            }
-            for (; k < nk; k++) E = E + term(k);
+            if (MODE == 0 && grey) run(std::true_type()); else run(std::false_type());
             pairs += nk;
         }
     }
