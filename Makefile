@@ -6,7 +6,7 @@ HIPCC ?= hipcc
 CXX ?= g++
 CSRC := raytracer_amd/csrc
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-            -fno-fast-math -Wall -Wno-unused-function
+            -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function
 HIP_SRCS := $(CSRC)/rt_api.hip $(CSRC)/rt_kernels.hip $(CSRC)/rt_bvh.hip $(CSRC)/rt_sort.hip $(CSRC)/rt_ploc.hip $(CSRC)/rt_sah.hip $(CSRC)/rt_bluenoise.hip
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
 HIP_HDRS := $(wildcard $(CSRC)/*.h) include/rt_abi.h
