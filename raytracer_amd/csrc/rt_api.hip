@@ -171,6 +171,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.tile_rank = c->tile_rank; a.tile_world = c->tile_world;
     a.tiles_x = (c->width + 31) / 32; a.tiles_y = (c->height + 31) / 32;
     u32 n_tiles = a.tiles_x * a.tiles_y;
+    a.tiles_x_magic = (a.tiles_x > 1 && (uint64_t) n_tiles * a.tiles_x < (1ull << 32)) ? (u32) ((1ull << 32) / a.tiles_x) + 1u : 0u;
     a.n_local_tiles = n_tiles > c->tile_rank ? (n_tiles - c->tile_rank + c->tile_world - 1) / c->tile_world : 0;
     a.n_paths = c->n_paths;
     a.probe = probe ? 1u : 0u;

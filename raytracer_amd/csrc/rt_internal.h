@@ -135,6 +135,7 @@ struct PassArgs {
     float fudge;                 // translucent_bssrdf_fudge or 0 when SSS is disabled (raytracing.cpp:653-657)
     u32 width, height;
     u32 tile_rank, tile_world, tiles_x, tiles_y, n_local_tiles;
+    u32 tiles_x_magic;           // floor(2^32 / tiles_x) + 1 when tile / tiles_x == umulhi(tile, magic) for every tile, else 0
     u32 n_paths;                 // capacity of the path arrays
     u32 probe;                   // 1 = translucent_rgen pass
     float tmin, tmax;
