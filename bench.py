@@ -81,8 +81,8 @@ def cpu_baseline(scene, budget_s, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -147,7 +147,9 @@ def main():
             dist.reduce(scratch, dst=0, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
         del scratch
-    rt.set_flags(scene.flags | _abi.RT_FLAG_TIME_KERNELS)
+    # every 8th frame of the timed region has its traverse / gather launches bracketed by HIP events on the library's
+    # stream (bracketing all of them costs 13 us of a 0.28 ms frame in event packets)
+    rt.set_flags(scene.flags | _abi.RT_FLAG_TIME_KERNELS | _abi.RT_FLAG_TIME_SAMPLED)
     rt.reset_stats()
 
     def fence():
@@ -200,8 +202,10 @@ def main():
         b_trav = 52.0 + 64.0 * model["n_node"] + 48.0 * model["n_tri"] + 64.0 * model["n_inst"]
         b_ray = 200.0 + 64.0 * model["n_node"] + 48.0 * model["n_tri"] + 64.0 * model["n_inst"]
         launches = max(stats["traverse_launches"], 1)
-        mean_launch_ms = stats["traverse_ms"] / launches
+        timed = max(stats["traverse_launches_timed"], 1)
+        mean_launch_ms = stats["traverse_ms"] / timed
         rays_per_launch = rays / launches
+        rays_timed = rays * timed / launches  # frames are statistically alike: the timed launches carry their share of the rays
         achieved = (b_trav * rays_per_launch) / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
         # HBM bytes per k_traverse launch from the committed PMC passes of this same command (tools/pmc_passes.sh +
         # tools/pmc_summary.py: FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as is); null for other workloads
@@ -233,7 +237,8 @@ def main():
                          # 96-byte instance records) times its own trees' counts; the figure above is SURVEY 8(d)'s model
                          "bytes_per_ray_traverse_this_layout": 52.0 + 32.0 * gpu_counts["n_node"] + 48.0 * gpu_counts["n_tri"] + 96.0 * gpu_counts["n_inst"],
                          "mean_launch_ms": mean_launch_ms, "rays_per_launch": rays_per_launch,
-                         "traverse_Mrays_s": rays / (stats["traverse_ms"] * 1e-3) / 1e6 if stats["traverse_ms"] > 0 else None,
+                         "traverse_Mrays_s": rays_timed / (stats["traverse_ms"] * 1e-3) / 1e6 if stats["traverse_ms"] > 0 else None,
+                         "launches_timed": stats["traverse_launches_timed"], "launches": stats["traverse_launches"],
                          "model_counts": model, "gpu_bvh_counts": gpu_counts},
             "cpu_baseline": cpu_line,
         }
@@ -243,10 +248,11 @@ def main():
                         "tlas_Minstances_per_s": stats["tlas_instances"] / (stats["tlas_build_ms"] * 1e-3) / 1e6 if stats["tlas_build_ms"] > 0 else None}
         if stats["gather_launches"] and stats["gather_ms"] > 0:
             # second hot loop: (hit, sample point) pairs of translucent_chit; 24 B per pair from LDS
-            pairs_s = stats["gather_pairs"] / (stats["gather_ms"] * 1e-3)
+            gtimed = max(stats["gather_launches_timed"], 1)
+            pairs_s = stats["gather_pairs"] * gtimed / stats["gather_launches"] / (stats["gather_ms"] * 1e-3)
             out["gather"] = {"kernel": "k_gather", "pairs_per_s": pairs_s, "lds_GB_per_s": 24.0 * pairs_s / 1e9,
-                             "mean_launch_ms": stats["gather_ms"] / stats["gather_launches"],
-                             "share_of_step": stats["gather_ms"] / (dt * 1e3)}
+                             "mean_launch_ms": stats["gather_ms"] / gtimed,
+                             "share_of_step": stats["gather_ms"] / gtimed * stats["gather_launches"] / (dt * 1e3)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -20,6 +20,7 @@ RT_FLAG_CAPTURE_HITS = 1 << 3
 RT_FLAG_COUNT_TRAVERSAL = 1 << 4
 RT_FLAG_TIME_KERNELS = 1 << 5
 RT_FLAG_ALL_PHASE_GROUPS = 1 << 6
+RT_FLAG_TIME_SAMPLED = 1 << 7
 
 VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3)])
 SAMPLE_POINT_DTYPE = np.dtype([("position", "<f4", 3), ("payload", "<f4", 3)])
@@ -63,7 +64,8 @@ class RtStats(C.Structure):
                 ("traverse_launches", C.c_uint64), ("traverse_ms", C.c_double), ("blas_build_ms", C.c_double),
                 ("tlas_build_ms", C.c_double), ("blas_triangles", C.c_uint64), ("tlas_instances", C.c_uint64),
                 ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64), ("wave_instance_steps", C.c_uint64),
-                ("max_ray_steps", C.c_uint64), ("gather_launches", C.c_uint64), ("gather_ms", C.c_double)]
+                ("max_ray_steps", C.c_uint64), ("gather_launches", C.c_uint64), ("gather_ms", C.c_double),
+                ("traverse_launches_timed", C.c_uint64), ("gather_launches_timed", C.c_uint64)]
 
 
 def load_library(path):

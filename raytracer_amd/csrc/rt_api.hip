@@ -89,7 +89,8 @@ struct rt_ctx {
     float* d_table[2] = { nullptr, nullptr }; int table_texels[2] = { 0, 0 }; int profile = 0;
     // stats
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, timed_gather; double traverse_ms = 0, gather_ms = 0;
-    uint64_t traverse_launches = 0, gather_launches = 0, primary_rays = 0;
+    uint64_t traverse_launches = 0, gather_launches = 0, primary_rays = 0, traverse_launches_timed = 0, gather_launches_timed = 0;
+    uint64_t dispatch_index = 0; // rt_dispatch_rays calls so far (RT_FLAG_TIME_SAMPLED times every 8th)
     double blas_build_ms = 0, tlas_build_ms = 0; uint64_t blas_triangles = 0;
     rt_ctx() { memset(&g, 0, sizeof g); memset(q, 0, sizeof q); memset(&hits, 0, sizeof hits); memset(&ps, 0, sizeof ps); memset(st, 0, sizeof st); memset(&gq, 0, sizeof gq); }
 };
@@ -211,12 +212,17 @@ uint64_t local_pixel_count(const PassArgs& a) {
     return n;
 }
 
+bool timing_now(const rt_ctx* c) {
+    return (c->flags & RT_FLAG_TIME_KERNELS) != 0 && (!(c->flags & RT_FLAG_TIME_SAMPLED) || c->dispatch_index % 8u == 0u);
+}
+
 int timed_traverse(rt_ctx* c, const PassArgs& a, u32 inq, bool primary, u32 sample_index) {
-    bool timing = (c->flags & RT_FLAG_TIME_KERNELS) != 0;
+    bool timing = timing_now(c);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) {
         RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
         RT_HIP(hipEventRecord(e0, c->stream));
+        c->traverse_launches_timed++;
     }
     int rc = launch_traverse(c->stream, a, inq, (c->flags & RT_FLAG_COUNT_TRAVERSAL) != 0, primary, sample_index);
     if (timing) { RT_HIP(hipEventRecord(e1, c->stream)); c->timed.emplace_back(e0, e1); }
@@ -226,11 +232,12 @@ int timed_traverse(rt_ctx* c, const PassArgs& a, u32 inq, bool primary, u32 samp
 }
 
 int timed_gather(rt_ctx* c, const PassArgs& a) {
-    bool timing = (c->flags & RT_FLAG_TIME_KERNELS) != 0;
+    bool timing = timing_now(c);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) {
         RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
         RT_HIP(hipEventRecord(e0, c->stream));
+        c->gather_launches_timed++;
     }
     int rc = launch_gather(c->stream, a);
     if (timing) { RT_HIP(hipEventRecord(e1, c->stream)); c->timed_gather.emplace_back(e0, e1); }
@@ -804,6 +811,7 @@ int rt_dispatch_rays(rt_ctx* c) {
     if (collect) RT_HIP(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream)); // :723-728
     rc = refresh_hg(); if (rc) return rc;
     rc = run_pass(c, false); if (rc) return rc;                                       // :734-741
+    c->dispatch_index++;
     c->g.accumulator_count += 1;                                                      // :744
     c->g.translucent_accumulator_count += (c->flags & RT_FLAG_COLLECT_SAMPLES) ? 1u : 0u; // :745
     return RT_OK;
@@ -860,6 +868,7 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
     out->wave_node_steps = ds.node_trips; out->wave_tri_steps = ds.tri_trips; out->wave_instance_steps = ds.inst_trips; out->max_ray_steps = ds.max_ray_steps;
     out->traverse_launches = c->traverse_launches; out->traverse_ms = c->traverse_ms;
     out->gather_launches = c->gather_launches; out->gather_ms = c->gather_ms;
+    out->traverse_launches_timed = c->traverse_launches_timed; out->gather_launches_timed = c->gather_launches_timed;
     out->blas_build_ms = c->blas_build_ms; out->tlas_build_ms = c->tlas_build_ms;
     out->blas_triangles = c->blas_triangles; out->tlas_instances = c->n_instances;
     return RT_OK;
@@ -870,6 +879,7 @@ int rt_reset_stats(rt_ctx* c) {
     int rc = drain_timers(c); if (rc) return rc;
     RT_HIP(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
     c->traverse_ms = 0; c->traverse_launches = 0; c->primary_rays = 0; c->gather_ms = 0; c->gather_launches = 0;
+    c->traverse_launches_timed = 0; c->gather_launches_timed = 0;
     return RT_OK;
 }
 
