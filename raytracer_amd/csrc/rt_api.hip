@@ -122,7 +122,7 @@ int ensure_path_buffers(rt_ctx* c) {
     RT_HIP(hipMalloc(&c->d_seg_count, sizeof(u32) * (4 * (size_t) segs + 1))); // 2 queues, gather, gather offsets
     RT_HIP(hipMemset(c->d_seg_count, 0, sizeof(u32) * (4 * (size_t) segs + 1)));
     c->n_segments_cap = segs;
-    const int n_arrays = 14 /* 2 queues x (6 + path) */ + 5 /* hits */ + 15 /* path state */ + 14 /* slot state x 2 */ + 9 /* gather */ + 42 /* stack spill */;
+    const int n_arrays = 14 /* 2 queues x (6 + path) */ + 5 /* hits */ + 15 /* path state */ + 14 /* slot state x 2 */ + 9 /* gather */ + 48 /* stack spill */;
     size_t stride = ((size_t) need + 63) & ~(size_t) 63;
     RT_HIP(hipMalloc(&c->d_arena, stride * 4 * n_arrays));
     float* p = c->d_arena;
@@ -143,7 +143,7 @@ int ensure_path_buffers(rt_ctx* c) {
     }
     c->gq.path = (u32*) take(); c->gq.hx = take(); c->gq.hy = take(); c->gq.hz = take(); c->gq.tf = take();
     c->gq.kx = take(); c->gq.ky = take(); c->gq.kz = take(); c->gq.ti = (int*) take();
-    c->d_stack_spill = (int*) p; p += 42 * stride;
+    c->d_stack_spill = (int*) p; p += 48 * stride;
     c->n_paths = (u32) stride;
     return RT_OK;
 }

@@ -150,7 +150,7 @@ struct PassArgs {
     u32* seg_count[2];           // rays per segment of the two ping-pong queues
     u32* gseg_count;             // gather items per segment
     u32* goff;                   // [n_segments + 1] exclusive scan of gseg_count (k_gather_offsets)
-    int* stack_spill;            // [42][n_paths] overflow of the per-lane traversal stack
+    int* stack_spill;            // [48][n_paths] overflow of the per-lane traversal stack
     DeviceStats* stats;
     RtHit* capture;              // [(bounces+1) * width*height] or null
     float* accumulator;          // RGBA32F

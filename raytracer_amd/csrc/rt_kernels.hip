@@ -20,9 +20,9 @@ namespace rti {
 using namespace rtd;
 
 static constexpr int TRAVERSE_WAVE   = 64;
-static constexpr int LDS_STACK_DEPTH = 22;  // entries per lane kept in LDS (rows 0-21 of the 8 KB per wave: 20 waves/CU = the VGPR limit);
-static constexpr int LDS_SIDE_ROW    = 23;  // row 22 is a dump row, rows 23-31 hold the top-level box-test constants while a ray is inside an instance
-static constexpr int OVF_STACK_DEPTH = 42;  // global spill; 64 entries with the sentinel; the host checks tlas_depth + 1 + blas_depth <= 64
+static constexpr int LDS_STACK_DEPTH = 16;  // entries per lane kept in LDS (rows 0-15 of the 6.5 KB per wave: 24 waves/CU = 6 per SIMD at 80 VGPRs);
+static constexpr int LDS_SIDE_ROW    = 17;  // row 16 is a dump row, rows 17-25 hold the top-level box-test constants while a ray is inside an instance
+static constexpr int OVF_STACK_DEPTH = 48;  // global spill; 64 entries with the sentinel; the host checks tlas_depth + 1 + blas_depth <= 64
 static constexpr int BT = 256;
 static constexpr int SEG = 1024;            // rays per queue segment = threads per raygen / shade workgroup
 
@@ -251,7 +251,7 @@ RT_DEV void traverse_counters_flush(const PassArgs& a, const TraverseCounters& c
 static constexpr u32 TASK_PARTS = 64, TASK_STRIDE = 32; // counters 128 bytes apart; counter TASK_PARTS counts the waves that are done
 template <bool COUNT, int WAVES_PER_SIMD, bool PRIMARY, bool PERSISTENT>
 __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq, u32 sample_index, u32 n_tasks) {
-    __shared__ int smem[32 * TRAVERSE_WAVE];
+    __shared__ int smem[26 * TRAVERSE_WAVE];
     TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
     u32 part = blockIdx.x % TASK_PARTS;
     // next task of partition `p`, or n_tasks when it has none left (wave-uniform; costs one atomic round trip)
@@ -784,7 +784,7 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
     if (!n) return RT_OK;
     dim3 grid = blocks(n, TRAVERSE_WAVE), block(TRAVERSE_WAVE);
     const u32 n_tasks = grid.x;
-    // 5 waves per SIMD = 96 VGPRs = what the LDS stacks allow as well (8 KB per wave)
+    // 6 waves per SIMD = 80 VGPRs = what the LDS stacks allow as well (6.5 KB per wave); the persistent variant keeps 5 (it needs 96)
     const bool persistent = a.persistent_slots != 0 && !count_traversal && (primary ? (a.persistent & 2u) != 0 : (a.persistent & 1u) != 0) && n_tasks > a.persistent_slots;
     if (persistent) {
         dim3 pgrid(a.persistent_slots);
@@ -792,10 +792,10 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
         else hipLaunchKernelGGL((k_traverse<false, 5, false, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
     } else if (primary) {
         if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-        else hipLaunchKernelGGL((k_traverse<false, 5, true, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        else hipLaunchKernelGGL((k_traverse<false, 6, true, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
     } else {
         if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-        else hipLaunchKernelGGL((k_traverse<false, 5, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        else hipLaunchKernelGGL((k_traverse<false, 6, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
     }
     RT_HIP(hipGetLastError());
     return RT_OK;
