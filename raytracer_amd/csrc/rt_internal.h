@@ -66,6 +66,7 @@ int ploc_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace& pw, u32 n, int le
 struct SahWorkspace { // rt_sah.hip (builder 2: top-down binned SAH)
     void* bins = nullptr; void* tasks[2] = { nullptr, nullptr }; void* decisions = nullptr;
     u32* counters = nullptr;                                   // tasks of the level, inner nodes, depth, tree cost (float)
+    void* sides = nullptr; // boxes of the two sides of every split of a level (k_sah_decide -> k_sah_number)
     rtd::BvhNode* alt_nodes = nullptr; u32* alt_perm = nullptr; // second tree when two builders compete (builder 4)
     u32 capacity = 0;
 };

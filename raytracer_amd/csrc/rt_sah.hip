@@ -2,9 +2,10 @@
 //
 // The tree is built breadth first, one level per step.  A step has three kernels:
 //   k_sah_bin    one thread per primitive: adds its box to one of 16 bins per axis of the node that owns it;
-//   k_sah_split  one workgroup: for every node of the level, sweeps the bins for the cheapest split, decides between a
-//                leaf and an inner node, numbers the new inner nodes and their children with a prefix scan (the numbering
-//                is breadth first and the same from run to run) and writes the 64-byte traversal nodes;
+//   k_sah_decide one thread per node of the level: sweeps its bins for the cheapest split, decides between a leaf and
+//                an inner node;
+//   k_sah_number one workgroup: numbers the new inner nodes and their children with a prefix scan (the numbering is
+//                breadth first and the same from run to run) and writes the 64-byte build nodes;
 //   k_sah_move   one thread per primitive: moves it to its child's side of the node's range.
 // Against the agglomerative PLOC build (rt_ploc.hip) this is the slower build (a few launches per level) and the
 // better tree: on the reference's bunny it cut nodes visited per ray by 10 % and traversal time by 12 % (DESIGN.md
@@ -55,16 +56,21 @@ __global__ void k_sah_clear(SahBin* __restrict__ bins, const u32* __restrict__ c
     bins[i] = b;
 }
 
+RT_DEV u32 wave_min_u32(u32 v) { for (int off = 32; off >= 1; off >>= 1) { u32 o = __shfl_xor(v, off); v = o < v ? o : v; } return v; }
+RT_DEV u32 wave_max_u32(u32 v) { for (int off = 32; off >= 1; off >>= 1) { u32 o = __shfl_xor(v, off); v = o > v ? o : v; } return v; }
+
 __global__ void k_sah_init(const Aabb* __restrict__ boxes, u32 n, u32* __restrict__ idx, u32* __restrict__ slot_task, SahTask* __restrict__ task0,
                            u32* __restrict__ counters) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    idx[i] = i; slot_task[i] = 0u;
-    const Aabb b = boxes[i];
-    for (int k = 0; k < 3; k++) {
-        float c = 0.5f * (b.lo[k] + b.hi[k]);
-        atomicMin(&task0->cb_lo[k], f2key(c)); atomicMax(&task0->cb_hi[k], f2key(c));
+    const bool live = i < n;
+    if (live) { idx[i] = i; slot_task[i] = 0u; }
+    const Aabb b = live ? boxes[i] : Aabb();
+    for (int k = 0; k < 3; k++) { // one atomic per wave: every primitive of the tree targets the same six words
+        const u32 key = f2key(0.5f * (b.lo[k] + b.hi[k]));
+        const u32 mn = wave_min_u32(live ? key : 0xffffffffu), mx = wave_max_u32(live ? key : 0u);
+        if ((threadIdx.x & 63u) == 0 && mn <= mx) { atomicMin(&task0->cb_lo[k], mn); atomicMax(&task0->cb_hi[k], mx); }
     }
+    if (!live) return;
     if (i == 0) { counters[0] = 1u; /* tasks of this level */ counters[1] = 0u; /* inner nodes so far */ counters[2] = 0u; /* depth */ }
 }
 
@@ -86,71 +92,125 @@ __global__ void k_sah_bin(const Aabb* __restrict__ boxes, const u32* __restrict_
     }
 }
 
+// the first levels (at most 16 nodes, so all primitives of the tree aim at <= 768 bins): bins are accumulated per
+// workgroup in LDS and flushed with one global atomic per touched word; with direct global atomics the binning of the
+// root of a 52,743-instance TLAS took 4.4 ms
+static constexpr u32 BIN_LDS_TASKS = 16;
+__global__ __launch_bounds__(BT) void k_sah_bin_lds(const Aabb* __restrict__ boxes, const u32* __restrict__ idx, const u32* __restrict__ slot_task, u32 n,
+                                                    const SahTask* __restrict__ tasks, SahBin* __restrict__ bins, const u32* __restrict__ counters) {
+    __shared__ u32 s_n[BIN_LDS_TASKS * 3 * NBINS], s_lo[BIN_LDS_TASKS * 3 * NBINS][3], s_hi[BIN_LDS_TASKS * 3 * NBINS][3];
+    const u32 n_bins = counters[0] * 3u * NBINS;
+    for (u32 b = threadIdx.x; b < n_bins; b += BT) { s_n[b] = 0; for (int k = 0; k < 3; k++) { s_lo[b][k] = 0xffffffffu; s_hi[b][k] = 0u; } }
+    __syncthreads();
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const u32 t = slot_task[i];
+        if (t != NO_TASK && tasks[t].count >= 2u) {
+            const SahTask& T = tasks[t];
+            const Aabb b = boxes[idx[i]];
+            for (int axis = 0; axis < 3; axis++) {
+                const float lo = key2f(T.cb_lo[axis]), hi = key2f(T.cb_hi[axis]);
+                if (!(hi > lo)) continue;
+                const u32 bin = (t * 3u + (u32) axis) * NBINS + (u32) sah_bin_of(0.5f * (b.lo[axis] + b.hi[axis]), lo, hi);
+                atomicAdd(&s_n[bin], 1u);
+                for (int k = 0; k < 3; k++) { atomicMin(&s_lo[bin][k], f2key(b.lo[k])); atomicMax(&s_hi[bin][k], f2key(b.hi[k])); }
+            }
+        }
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < n_bins; b += BT) {
+        if (s_n[b] == 0u) continue;
+        atomicAdd(&bins[b].n, s_n[b]);
+        for (int k = 0; k < 3; k++) { atomicMin(&bins[b].lo[k], s_lo[b][k]); atomicMax(&bins[b].hi[k], s_hi[b][k]); }
+    }
+}
+
 RT_DEV float sah_half_area(const float* lo, const float* hi) {
     float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
     return x * y + y * z + z * x;
 }
 
-// one workgroup of 1024 threads walks all tasks of the level
-__global__ __launch_bounds__(1024) void k_sah_split(const SahTask* __restrict__ tasks, const SahBin* __restrict__ bins, SahDecision* __restrict__ dec,
-                                                    SahTask* __restrict__ next, BvhNode* __restrict__ nodes, u32* __restrict__ counters,
-                                                    float sah_tri, int leaf_max) {
+// Split decisions of a level, one thread per task (any number of workgroups): sweeps the bins of the task for the
+// cheapest split, decides between a leaf and an inner node and leaves the decision and the boxes of the two sides for
+// k_sah_number.
+struct SahSides { float l[6], r[6]; };
+__global__ __launch_bounds__(BT) void k_sah_decide(const SahTask* __restrict__ tasks, const SahBin* __restrict__ bins, SahDecision* __restrict__ dec,
+                                                   SahSides* __restrict__ sides, u32* __restrict__ counters, float sah_tri, int leaf_max) {
+    const u32 n_tasks = counters[0];
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 max_depth = 0;
+    if (t < n_tasks) {
+        SahDecision D;
+        D.axis = -2; D.split_bin = 0; D.n_left = 0; D.child_task = 0; D.cnt_left = 0; D.cnt_right = 0;
+        float lbox[6] = { 0, 0, 0, 0, 0, 0 }, rbox[6] = { 0, 0, 0, 0, 0, 0 };
+        const SahTask T = tasks[t];
+        max_depth = T.depth;
+        if (T.count >= 2u) {
+            float best = 3.0e38f, area = 0.0f;
+            for (int axis = 0; axis < 3; axis++) {
+                const SahBin* b = bins + ((size_t) t * 3 + axis) * NBINS;
+                if (!(key2f(T.cb_hi[axis]) > key2f(T.cb_lo[axis]))) continue;
+                // areas of the suffixes, then a forward sweep
+                float ra[NBINS]; u32 rn[NBINS];
+                float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f }; u32 nn = 0;
+                for (int k = NBINS - 1; k > 0; k--) {
+                    if (b[k].n) for (int c = 0; c < 3; c++) { lo[c] = fminf(lo[c], key2f(b[k].lo[c])); hi[c] = fmaxf(hi[c], key2f(b[k].hi[c])); }
+                    nn += b[k].n; rn[k] = nn; ra[k] = nn ? sah_half_area(lo, hi) : 0.0f;
+                }
+                if (b[0].n) for (int c = 0; c < 3; c++) { lo[c] = fminf(lo[c], key2f(b[0].lo[c])); hi[c] = fmaxf(hi[c], key2f(b[0].hi[c])); }
+                area = sah_half_area(lo, hi); // the whole node (the same for every axis with a spread)
+                for (int c = 0; c < 3; c++) { lo[c] = 3.0e38f; hi[c] = -3.0e38f; } nn = 0;
+                for (int k = 0; k < NBINS - 1; k++) {
+                    if (b[k].n) for (int c = 0; c < 3; c++) { lo[c] = fminf(lo[c], key2f(b[k].lo[c])); hi[c] = fmaxf(hi[c], key2f(b[k].hi[c])); }
+                    nn += b[k].n;
+                    if (nn == 0u || rn[k + 1] == 0u) continue;
+                    float cost = sah_half_area(lo, hi) * (float) nn + ra[k + 1] * (float) rn[k + 1];
+                    if (cost < best) { best = cost; D.axis = axis; D.split_bin = k + 1; D.n_left = nn; }
+                }
+            }
+            if (D.axis >= 0) {
+                const float leaf_cost = sah_tri * (float) T.count * area, split_cost = area + sah_tri * best;
+                if (T.parent_slot >= 0 && (int) T.count <= leaf_max && leaf_cost <= split_cost) D.axis = -2;
+            } else if (T.parent_slot < 0 || (int) T.count > leaf_max) { // leaf_max <= 8, the most a leaf link encodes
+                D.axis = -1; D.n_left = (T.count + 1u) / 2u; // all centres coincide: cut the range in the middle
+            }
+            if (D.axis >= 0) { // boxes of the two sides
+                const SahBin* b = bins + ((size_t) t * 3 + D.axis) * NBINS;
+                for (int c = 0; c < 3; c++) { lbox[c] = 3.0e38f; lbox[3 + c] = -3.0e38f; rbox[c] = 3.0e38f; rbox[3 + c] = -3.0e38f; }
+                for (int k = 0; k < NBINS; k++) {
+                    if (!b[k].n) continue;
+                    float* o = k < D.split_bin ? lbox : rbox;
+                    for (int c = 0; c < 3; c++) { o[c] = fminf(o[c], key2f(b[k].lo[c])); o[3 + c] = fmaxf(o[3 + c], key2f(b[k].hi[c])); }
+                }
+            }
+        } // (a single primitive at the root is emitted by the caller)
+        if (D.axis < 0) // leaf, or middle cut of coinciding primitives: both halves keep the node's box
+            for (int c = 0; c < 3; c++) { lbox[c] = T.lo[c]; lbox[3 + c] = T.hi[c]; rbox[c] = T.lo[c]; rbox[3 + c] = T.hi[c]; }
+        dec[t] = D;
+        SahSides sd;
+        for (int c = 0; c < 6; c++) { sd.l[c] = lbox[c]; sd.r[c] = rbox[c]; }
+        sides[t] = sd;
+    }
+    // depth of the tree so far
+    for (int off = 32; off >= 1; off >>= 1) { u32 o = __shfl_xor(max_depth, off); max_depth = o > max_depth ? o : max_depth; }
+    if ((threadIdx.x & 63u) == 0 && max_depth) atomicMax(&counters[2], max_depth);
+}
+
+// One workgroup of 1024 threads numbers the new inner nodes of the level and their child tasks with a prefix scan over
+// the decisions (breadth first, the same from run to run) and writes the nodes and the tasks of the next level.
+__global__ __launch_bounds__(1024) void k_sah_number(const SahTask* __restrict__ tasks, SahDecision* __restrict__ dec, const SahSides* __restrict__ sides,
+                                                     SahTask* __restrict__ next, BvhNode* __restrict__ nodes, u32* __restrict__ counters) {
     __shared__ u32 s_wave[16];
     __shared__ u32 s_carry;
     const u32 n_tasks = counters[0], node_base = counters[1];
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    u32 max_depth = 0;
     for (u32 t0 = 0; t0 < n_tasks; t0 += 1024u) {
         const u32 t = t0 + threadIdx.x;
         const bool live = t < n_tasks;
-        SahTask T; SahDecision D;
-        D.axis = -2; D.split_bin = 0; D.n_left = 0; D.child_task = 0; D.cnt_left = 0; D.cnt_right = 0;
-        float lbox[6] = { 0, 0, 0, 0, 0, 0 }, rbox[6] = { 0, 0, 0, 0, 0, 0 };
-        if (live) {
-            T = tasks[t];
-            max_depth = T.depth > max_depth ? T.depth : max_depth;
-            if (T.count >= 2u) {
-                float best = 3.0e38f, area = 0.0f;
-                for (int axis = 0; axis < 3; axis++) {
-                    const SahBin* b = bins + ((size_t) t * 3 + axis) * NBINS;
-                    if (!(key2f(T.cb_hi[axis]) > key2f(T.cb_lo[axis]))) continue;
-                    // areas of the suffixes, then a forward sweep
-                    float ra[NBINS]; u32 rn[NBINS];
-                    float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f }; u32 nn = 0;
-                    for (int k = NBINS - 1; k > 0; k--) {
-                        if (b[k].n) for (int c = 0; c < 3; c++) { lo[c] = fminf(lo[c], key2f(b[k].lo[c])); hi[c] = fmaxf(hi[c], key2f(b[k].hi[c])); }
-                        nn += b[k].n; rn[k] = nn; ra[k] = nn ? sah_half_area(lo, hi) : 0.0f;
-                    }
-                    if (b[0].n) for (int c = 0; c < 3; c++) { lo[c] = fminf(lo[c], key2f(b[0].lo[c])); hi[c] = fmaxf(hi[c], key2f(b[0].hi[c])); }
-                    area = sah_half_area(lo, hi); // the whole node (the same for every axis with a spread)
-                    for (int c = 0; c < 3; c++) { lo[c] = 3.0e38f; hi[c] = -3.0e38f; } nn = 0;
-                    for (int k = 0; k < NBINS - 1; k++) {
-                        if (b[k].n) for (int c = 0; c < 3; c++) { lo[c] = fminf(lo[c], key2f(b[k].lo[c])); hi[c] = fmaxf(hi[c], key2f(b[k].hi[c])); }
-                        nn += b[k].n;
-                        if (nn == 0u || rn[k + 1] == 0u) continue;
-                        float cost = sah_half_area(lo, hi) * (float) nn + ra[k + 1] * (float) rn[k + 1];
-                        if (cost < best) { best = cost; D.axis = axis; D.split_bin = k + 1; D.n_left = nn; }
-                    }
-                }
-                if (D.axis >= 0) {
-                    const float leaf_cost = sah_tri * (float) T.count * area, split_cost = area + sah_tri * best;
-                    if (T.parent_slot >= 0 && (int) T.count <= leaf_max && leaf_cost <= split_cost) D.axis = -2;
-                } else if (T.parent_slot < 0 || (int) T.count > leaf_max) { // leaf_max <= 8, the most a leaf link encodes
-                    D.axis = -1; D.n_left = (T.count + 1u) / 2u; // all centres coincide: cut the range in the middle
-                }
-                if (D.axis >= 0) { // boxes of the two sides
-                    const SahBin* b = bins + ((size_t) t * 3 + D.axis) * NBINS;
-                    for (int c = 0; c < 3; c++) { lbox[c] = 3.0e38f; lbox[3 + c] = -3.0e38f; rbox[c] = 3.0e38f; rbox[3 + c] = -3.0e38f; }
-                    for (int k = 0; k < NBINS; k++) {
-                        if (!b[k].n) continue;
-                        float* o = k < D.split_bin ? lbox : rbox;
-                        for (int c = 0; c < 3; c++) { o[c] = fminf(o[c], key2f(b[k].lo[c])); o[3 + c] = fmaxf(o[3 + c], key2f(b[k].hi[c])); }
-                    }
-                }
-            } else if (T.parent_slot < 0) { D.axis = -2; } // a single primitive at the root is emitted by the caller
-        }
+        SahDecision D; D.axis = -2; D.n_left = 0;
+        if (live) D = dec[t];
         const bool split = live && D.axis >= -1;
         // exclusive scan of `split` over the tasks, in task order
         const unsigned long long m = __ballot(split);
@@ -159,21 +219,21 @@ __global__ __launch_bounds__(1024) void k_sah_split(const SahTask* __restrict__ 
         u32 rank = s_carry + (u32) __popcll(m & ((1ull << lane) - 1ull)), total = 0;
         for (u32 w = 0; w < 16u; w++) { u32 c = s_wave[w]; if (w < wave) rank += c; total += c; }
         if (live) {
+            const SahTask T = tasks[t];
             int link;
             if (split) {
+                const SahSides sd = sides[t];
                 const u32 id = node_base + rank;
                 link = (int) id;
-                D.child_task = 2u * rank;
+                dec[t].child_task = 2u * rank;
                 SahTask L, R;
                 L.first = T.first; L.count = D.n_left; L.parent_slot = (int) (2u * id); L.depth = T.depth + 1u;
                 R.first = T.first + D.n_left; R.count = T.count - D.n_left; R.parent_slot = (int) (2u * id + 1u); R.depth = T.depth + 1u;
                 for (int c = 0; c < 3; c++) { L.cb_lo[c] = 0xffffffffu; L.cb_hi[c] = 0u; R.cb_lo[c] = 0xffffffffu; R.cb_hi[c] = 0u; }
-                if (D.axis < 0) // middle cut of coinciding primitives: both halves keep the node's box
-                    for (int c = 0; c < 3; c++) { lbox[c] = T.lo[c]; lbox[3 + c] = T.hi[c]; rbox[c] = T.lo[c]; rbox[3 + c] = T.hi[c]; }
-                for (int c = 0; c < 3; c++) { L.lo[c] = lbox[c]; L.hi[c] = lbox[3 + c]; R.lo[c] = rbox[c]; R.hi[c] = rbox[3 + c]; }
+                for (int c = 0; c < 3; c++) { L.lo[c] = sd.l[c]; L.hi[c] = sd.l[3 + c]; R.lo[c] = sd.r[c]; R.hi[c] = sd.r[3 + c]; }
                 next[2u * rank] = L; next[2u * rank + 1u] = R;
                 BvhNode nd;
-                for (int c = 0; c < 3; c++) { nd.lo0[c] = lbox[c]; nd.hi0[c] = lbox[3 + c]; nd.lo1[c] = rbox[c]; nd.hi1[c] = rbox[3 + c]; }
+                for (int c = 0; c < 3; c++) { nd.lo0[c] = sd.l[c]; nd.hi0[c] = sd.l[3 + c]; nd.lo1[c] = sd.r[c]; nd.hi1[c] = sd.r[3 + c]; }
                 nd.c0 = 0; nd.c1 = 0; nd.bound = 0.0f; nd.depth = 0;
                 nodes[id] = nd;
             } else link = ~(int) ((T.first << 3) | (T.count - 1u));
@@ -181,16 +241,11 @@ __global__ __launch_bounds__(1024) void k_sah_split(const SahTask* __restrict__ 
                 BvhNode* p = nodes + (T.parent_slot >> 1);
                 if (T.parent_slot & 1) p->c1 = link; else p->c0 = link;
             }
-            dec[t] = D;
         }
         __syncthreads();
         if (threadIdx.x == 0) s_carry += total;
         __syncthreads();
     }
-    // depth of the tree so far
-    for (int off = 32; off >= 1; off >>= 1) { u32 o = __shfl_xor(max_depth, off); max_depth = o > max_depth ? o : max_depth; }
-    if (lane == 0) atomicMax(&counters[2], max_depth);
-    __syncthreads();
     if (threadIdx.x == 0) { counters[0] = 2u * s_carry; counters[1] = node_base + s_carry; }
 }
 
@@ -198,24 +253,66 @@ __global__ void k_sah_move(const Aabb* __restrict__ boxes, const u32* __restrict
                            const SahTask* __restrict__ tasks, SahDecision* __restrict__ dec, SahTask* __restrict__ next,
                            u32* __restrict__ idx_out, u32* __restrict__ slot_task_out) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u32 t = slot_task[i], prim = idx[i];
-    if (t == NO_TASK) { idx_out[i] = prim; slot_task_out[i] = NO_TASK; return; }
+    const bool live = i < n;
+    const u32 t = live ? slot_task[i] : NO_TASK, prim = live ? idx[i] : 0u;
+    bool moving = false, left = false;
+    Aabb b = Aabb();
+    if (live) {
+        if (t == NO_TASK || dec[t].axis == -2) { idx_out[i] = prim; slot_task_out[i] = NO_TASK; } // settled in a leaf
+        else {
+            moving = true;
+            const SahDecision& D = dec[t];
+            const SahTask& T = tasks[t];
+            b = boxes[prim];
+            if (D.axis >= 0) left = sah_bin_of(0.5f * (b.lo[D.axis] + b.hi[D.axis]), key2f(T.cb_lo[D.axis]), key2f(T.cb_hi[D.axis])) < D.split_bin;
+            else left = (i - T.first) < D.n_left;
+        }
+    }
+    // Primitives of a node are contiguous, so in the upper levels a whole wave belongs to one node: then the wave takes
+    // its places in the two child ranges with one atomic per side and reduces the children's centroid bounds itself
+    // (per-lane atomics on the few words of a big node cost 2.5 ms for the root of a 52,743-instance TLAS).
+    const unsigned long long m_move = __ballot(moving);
+    if (m_move == 0ull) return;
+    const u32 lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long) m_move) - 1;
+    const u32 t0 = (u32) __shfl((int) t, leader);
+    const bool uniform = __ballot(moving && t == t0) == m_move;
+    u32 keys[3];
+    for (int k = 0; k < 3; k++) keys[k] = f2key(0.5f * (b.lo[k] + b.hi[k]));
+    if (uniform) {
+        SahDecision& D = dec[t0];
+        const SahTask& T = tasks[t0];
+        const unsigned long long m_left = __ballot(moving && left), m_right = m_move & ~m_left;
+        u32 base_l = 0, base_r = 0;
+        if ((int) lane == leader) {
+            if (m_left) base_l = atomicAdd(&D.cnt_left, (u32) __popcll(m_left));
+            if (m_right) base_r = atomicAdd(&D.cnt_right, (u32) __popcll(m_right));
+        }
+        base_l = (u32) __shfl((int) base_l, leader); base_r = (u32) __shfl((int) base_r, leader);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (moving) {
+            const u32 pos = left ? T.first + base_l + (u32) __popcll(m_left & below) : T.first + D.n_left + base_r + (u32) __popcll(m_right & below);
+            idx_out[pos] = prim; slot_task_out[pos] = D.child_task + (left ? 0u : 1u);
+        }
+        for (int side = 0; side < 2; side++) {
+            const bool mine = moving && (left == (side == 0));
+            if ((side == 0 ? m_left : m_right) == 0ull) continue;
+            SahTask& C = next[D.child_task + (u32) side];
+            for (int k = 0; k < 3; k++) {
+                const u32 mn = wave_min_u32(mine ? keys[k] : 0xffffffffu), mx = wave_max_u32(mine ? keys[k] : 0u);
+                if ((int) lane == leader) { atomicMin(&C.cb_lo[k], mn); atomicMax(&C.cb_hi[k], mx); }
+            }
+        }
+        return;
+    }
+    if (!moving) return;
     SahDecision& D = dec[t];
-    if (D.axis == -2) { idx_out[i] = prim; slot_task_out[i] = NO_TASK; return; } // settled in a leaf
     const SahTask& T = tasks[t];
-    const Aabb b = boxes[prim];
-    bool left;
-    if (D.axis >= 0) left = sah_bin_of(0.5f * (b.lo[D.axis] + b.hi[D.axis]), key2f(T.cb_lo[D.axis]), key2f(T.cb_hi[D.axis])) < D.split_bin;
-    else left = (i - T.first) < D.n_left;
     const u32 pos = left ? T.first + atomicAdd(&D.cnt_left, 1u) : T.first + D.n_left + atomicAdd(&D.cnt_right, 1u);
     const u32 child = D.child_task + (left ? 0u : 1u);
     idx_out[pos] = prim; slot_task_out[pos] = child;
     SahTask& C = next[child];
-    for (int k = 0; k < 3; k++) {
-        const u32 key = f2key(0.5f * (b.lo[k] + b.hi[k]));
-        atomicMin(&C.cb_lo[k], key); atomicMax(&C.cb_hi[k], key);
-    }
+    for (int k = 0; k < 3; k++) { atomicMin(&C.cb_lo[k], keys[k]); atomicMax(&C.cb_hi[k], keys[k]); }
 }
 
 // root record; for a top-level tree the one-primitive leaf links (first << 3) become instance links
@@ -268,6 +365,7 @@ int sah_workspace_reserve(SahWorkspace& w, u32 n) {
     RT_HIP(hipMalloc(&w.tasks[0], sizeof(SahTask) * (size_t) cap));
     RT_HIP(hipMalloc(&w.tasks[1], sizeof(SahTask) * (size_t) cap));
     RT_HIP(hipMalloc(&w.decisions, sizeof(SahDecision) * (size_t) cap));
+    RT_HIP(hipMalloc(&w.sides, sizeof(SahSides) * (size_t) cap));
     RT_HIP(hipMalloc(&w.counters, 4 * sizeof(u32)));
     RT_HIP(hipMalloc(&w.alt_nodes, sizeof(BvhNode) * (size_t) cap));
     RT_HIP(hipMalloc(&w.alt_perm, 4 * (size_t) cap));
@@ -275,7 +373,7 @@ int sah_workspace_reserve(SahWorkspace& w, u32 n) {
     return RT_OK;
 }
 void sah_workspace_free(SahWorkspace& w) {
-    void* ptrs[] = { w.bins, w.tasks[0], w.tasks[1], w.decisions, w.counters, w.alt_nodes, w.alt_perm };
+    void* ptrs[] = { w.bins, w.tasks[0], w.tasks[1], w.decisions, w.sides, w.counters, w.alt_nodes, w.alt_perm };
     for (void* p : ptrs) if (p) (void) hipFree(p);
     w = SahWorkspace();
 }
@@ -298,9 +396,14 @@ int sah_build(hipStream_t s, LbvhWorkspace& w, SahWorkspace& sw, u32 n, int leaf
     for (int level = 0; level < 96 && n_tasks > 0; level++) {
         const u32 task_bound = level < 20 ? ((1u << level) < n ? (1u << level) : n) : n; // a level has at most 2^level tasks
         hipLaunchKernelGGL(k_sah_clear, grid_for(task_bound * 3 * NBINS), dim3(BT), 0, s, (SahBin*) sw.bins, (const u32*) sw.counters);
-        hipLaunchKernelGGL(k_sah_bin, grid_for(n), dim3(BT), 0, s, w.boxes, idx[cur], slot[cur], n, (const SahTask*) sw.tasks[cur], (SahBin*) sw.bins);
-        hipLaunchKernelGGL(k_sah_split, dim3(1), dim3(1024), 0, s, (const SahTask*) sw.tasks[cur], (const SahBin*) sw.bins,
-                           (SahDecision*) sw.decisions, (SahTask*) sw.tasks[cur ^ 1], nodes_out, sw.counters, sah_tri, leaf_max);
+        if (task_bound <= BIN_LDS_TASKS)
+            hipLaunchKernelGGL(k_sah_bin_lds, grid_for(n), dim3(BT), 0, s, w.boxes, idx[cur], slot[cur], n, (const SahTask*) sw.tasks[cur], (SahBin*) sw.bins, (const u32*) sw.counters);
+        else
+            hipLaunchKernelGGL(k_sah_bin, grid_for(n), dim3(BT), 0, s, w.boxes, idx[cur], slot[cur], n, (const SahTask*) sw.tasks[cur], (SahBin*) sw.bins);
+        hipLaunchKernelGGL(k_sah_decide, grid_for(task_bound), dim3(BT), 0, s, (const SahTask*) sw.tasks[cur], (const SahBin*) sw.bins,
+                           (SahDecision*) sw.decisions, (SahSides*) sw.sides, sw.counters, sah_tri, leaf_max);
+        hipLaunchKernelGGL(k_sah_number, dim3(1), dim3(1024), 0, s, (const SahTask*) sw.tasks[cur], (SahDecision*) sw.decisions,
+                           (const SahSides*) sw.sides, (SahTask*) sw.tasks[cur ^ 1], nodes_out, sw.counters);
         hipLaunchKernelGGL(k_sah_move, grid_for(n), dim3(BT), 0, s, w.boxes, idx[cur], slot[cur], n, (const SahTask*) sw.tasks[cur],
                            (SahDecision*) sw.decisions, (SahTask*) sw.tasks[cur ^ 1], idx[cur ^ 1], slot[cur ^ 1]);
         cur ^= 1;
