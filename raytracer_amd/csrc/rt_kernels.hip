@@ -492,20 +492,25 @@ static constexpr int GATHER_TABLE_MAX = 2048;  // texels kept in LDS: 32 KB (ray
 
 struct alignas(16) GatherPoint { float px, py, pz, pad0, wx, wy, wz, pad1; };
 
-// S8 with the table in LDS as (r, g, b, 0) per texel; same arithmetic as sample_bssrdf_table, written without
-// branches (clamped addresses, selects) so that the unrolled gather loop can overlap the chains of several points
+// S8 with the table in LDS as (r, g, b, 0) per texel, stored with its zero border: entries 0 and 1 are texels -2 and
+// -1, entries 2..n+1 the texels, entries n+2 and n+3 zero again (tab_fill_lds).  Same arithmetic as
+// sample_bssrdf_table for every finite coordinate; the border replaces the range checks (a clamp of the texel index
+// instead of seven compares, seven selects and a branch): outside the table both texels are 0 and so is 0 + f * 0.
 RT_DEV f3 sample_bssrdf_table_lds(const float4* tab, int n, float u) {
-    float x = u * (float) n - 0.5f;
-    float fl = floorf(x);
-    float f = x - fl;
-    const bool in_range = fl >= -1.0f && fl < (float) n;
-    int i0 = in_range ? (int) fl : -2, i1 = i0 + 1;
-    const bool ok0 = i0 >= 0 && i0 < n, ok1 = i1 >= 0 && i1 < n;
-    float4 t0 = tab[ok0 ? i0 : 0], t1 = tab[ok1 ? i1 : 0];
-    f3 ta = ok0 ? mk3(t0.x, t0.y, t0.z) : mk3(0.0f, 0.0f, 0.0f);
-    f3 tb = ok1 ? mk3(t1.x, t1.y, t1.z) : mk3(0.0f, 0.0f, 0.0f);
-    f3 r = ta + f * (tb - ta);
-    return in_range ? r : mk3(0.0f, 0.0f, 0.0f);
+    const float x = u * (float) n - 0.5f;
+    const float fl = floorf(x);
+    const float f = x - fl;
+    const int k0 = (int) fminf(fmaxf(fl, -2.0f), (float) n) + 2; // 0 .. n + 2
+    const float4 t0 = tab[k0], t1 = tab[k0 + 1];
+    const f3 ta = mk3(t0.x, t0.y, t0.z), tb = mk3(t1.x, t1.y, t1.z);
+    return ta + f * (tb - ta);
+}
+template <int BLOCK>
+RT_DEV void tab_fill_lds(float4* tab, const float* table, int n) {
+    for (int t = threadIdx.x; t < n + 4; t += BLOCK) {
+        const int k = t - 2;
+        tab[t] = (k >= 0 && k < n) ? make_float4(table[3 * k], table[3 * k + 1], table[3 * k + 2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
 }
 
 // Gather items sit at the front of their 1024-slot segments; after the first bounce most segments hold only a few
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(SEG) void k_gather_offsets(PassArgs a) {
 template <int MODE>
 __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
     __shared__ GatherPoint s_pts[GATHER_TILE];
-    __shared__ float4 s_tab[GATHER_TABLE_MAX];
+    __shared__ float4 s_tab[GATHER_TABLE_MAX + 4];
     __shared__ int s_next;
     const u32 n_items = a.goff[a.n_segments];
     if (blockIdx.x * GATHER_BLOCK >= n_items) return; // uniform
@@ -557,8 +562,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
     const int my_ti = active ? g.ti[i] : -1;
     const float scale = a.g.translucent_bssrdf_scale;
     if (MODE == 1)
-        for (int t = threadIdx.x; t < a.bssrdf_texels; t += GATHER_BLOCK)
-            s_tab[t] = make_float4(a.bssrdf_table[3 * t], a.bssrdf_table[3 * t + 1], a.bssrdf_table[3 * t + 2], 0.0f);
+        tab_fill_lds<GATHER_BLOCK>(s_tab, a.bssrdf_table, a.bssrdf_texels);
     // radiance-only arithmetic (covered by the 1e-4 tolerance): fudge / scale^2 is folded into one
     // factor, and the dipole uses the hardware sqrt / rcp / exp2.  The table coordinate radius / scale stays (all but)
     // correctly rounded -- near the end of the profile's support the texels are ~1e-7 and an ulp of the coordinate is a
@@ -678,7 +682,7 @@ static constexpr int HG_STACK = 24; // the walk holds at most depth + 1 entries;
 // MODE as in k_gather.  One hit per lane, per-lane preorder walk with the stack in LDS.
 template <int MODE>
 __global__ __launch_bounds__(GATHER_BLOCK) void k_gather_hg(PassArgs a) {
-    __shared__ float4 s_tab[GATHER_TABLE_MAX];
+    __shared__ float4 s_tab[GATHER_TABLE_MAX + 4];
     __shared__ u32 s_stack[HG_STACK * GATHER_BLOCK];
     const u32 n_items = a.goff[a.n_segments];
     if (blockIdx.x * GATHER_BLOCK >= n_items) return; // uniform
@@ -692,8 +696,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather_hg(PassArgs a) {
         i = lo * SEG + (jj - a.goff[lo]);
     }
     if (MODE == 1) {
-        for (int t = threadIdx.x; t < a.bssrdf_texels; t += GATHER_BLOCK)
-            s_tab[t] = make_float4(a.bssrdf_table[3 * t], a.bssrdf_table[3 * t + 1], a.bssrdf_table[3 * t + 2], 0.0f);
+        tab_fill_lds<GATHER_BLOCK>(s_tab, a.bssrdf_table, a.bssrdf_texels);
         __syncthreads();
     }
     if (!active) return;
