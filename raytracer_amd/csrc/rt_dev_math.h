@@ -212,6 +212,7 @@ RT_DEV f3 sample_bssrdf_table(const float* tab /* rgb interleaved */, int n, flo
 // raytracing.hlsl:278-301, one channel.  The radius-independent terms are hoisted by the caller (DipoleConst).
 struct DipoleConst {
     float z_real, z_virtual, sigma_tr, scale; // scale = albedo / (2 tau)
+    float exp2_rate, a_real, a_virtual;       // dipole_eval_fast only: -sigma_tr log2(e), scale z exp(-sigma_tr z) per pole
 };
 RT_DEV DipoleConst dipole_constants(float sigma_s, float sigma_a, float eta) {
     DipoleConst c;
@@ -223,6 +224,9 @@ RT_DEV DipoleConst dipole_constants(float sigma_s, float sigma_a, float eta) {
     c.z_real = mean_free_path;
     c.z_virtual = mean_free_path * (1.0f + 1.25f * (1.0f + diffuse_fresnel) / (1.0f - diffuse_fresnel));
     c.scale = albedo / (2.0f * RT_TAU_F);
+    c.exp2_rate = -c.sigma_tr * 1.44269504088896341f;
+    c.a_real = c.scale * c.z_real * expf(-c.sigma_tr * c.z_real);
+    c.a_virtual = c.scale * c.z_virtual * expf(-c.sigma_tr * c.z_virtual);
     return c;
 }
 RT_DEV float dipole_eval(const DipoleConst& c, float radius) {
@@ -280,15 +284,18 @@ RT_DEV float fast_exp(float x) {
     return expf(x);
 #endif
 }
-// dipole_eval with hardware rcp / exp2: same formula, a few ulp from the IEEE evaluation
+// dipole_eval with hardware rcp / exp2 and exp(-sigma (r + z)) split as exp(-sigma r) exp(-sigma z), so that both poles
+// share one exponential per pair and the per-pole factors come from dipole_constants: the same function to a few ulp
 RT_DEV float dipole_eval_fast(const DipoleConst& c, float radius) {
-    float d_real = radius + c.z_real, d_virtual = radius + c.z_virtual;
-    float ir = fast_rcp(d_real), iv = fast_rcp(d_virtual);
-    float c_real = c.z_real * (c.sigma_tr + ir);
-    float c_virtual = c.z_virtual * (c.sigma_tr + iv);
-    float m_real = c_real * fast_exp(-c.sigma_tr * d_real) * (ir * ir);
-    float m_virtual = c_virtual * fast_exp(-c.sigma_tr * d_virtual) * (iv * iv);
-    float r = c.scale * (m_real + m_virtual);
+    float ir = fast_rcp(radius + c.z_real), iv = fast_rcp(radius + c.z_virtual);
+#if defined(__HIPCC__)
+    float e = __builtin_amdgcn_exp2f(radius * c.exp2_rate);
+#else
+    float e = expf(-c.sigma_tr * radius);
+#endif
+    float m_real = (c.sigma_tr + ir) * (ir * ir);
+    float m_virtual = (c.sigma_tr + iv) * (iv * iv);
+    float r = e * (c.a_real * m_real + c.a_virtual * m_virtual);
     return r > 0.0f ? r : 0.0f;
 }
 
