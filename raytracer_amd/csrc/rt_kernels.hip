@@ -608,10 +608,12 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
             // the scheduler from interleaving their chains.
             auto run = [&](auto grey_tag) {
                 constexpr bool GREY = decltype(grey_tag)::value;
-                auto term = [&](u32 k) -> f3 {
+                struct Term { f3 bs, w; };
+                auto term = [&](u32 k) -> Term {
                     const GatherPoint gp = s_pts[k];
                     f3 dp = mk3(gp.px, gp.py, gp.pz) - hit;
-                    float radius = MODE != 0 ? sqrt_refined(dot3(dp, dp)) : fast_sqrt(dot3(dp, dp));
+                    float radius = MODE != 0 ? sqrt_refined(dot3(dp, dp))
+                                             : fast_sqrt(__builtin_fmaf(dp.z, dp.z, __builtin_fmaf(dp.y, dp.y, dp.x * dp.x)));
                     f3 bs;
                     if (MODE != 0) {
                         const float coord = div_by_shared(radius, scale, inv_scale);
@@ -620,14 +622,18 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
                         bs = fudge_over_z * tv;                                                                  // :272-276
                     } else if (GREY) { float v = dipole_eval_fast(cr, radius); bs = mk3(v, v, v); }               // :278-301
                     else bs = mk3(dipole_eval_fast(cr, radius), dipole_eval_fast(cg, radius), dipole_eval_fast(cb, radius));
-                    return bs * mk3(gp.wx, gp.wy, gp.wz);
+                    return Term{bs, mk3(gp.wx, gp.wy, gp.wz)};
+                };
+                // the sum runs in index order, one fused multiply-add per channel and pair
+                auto add = [&](const Term& c) {
+                    E.x = __builtin_fmaf(c.bs.x, c.w.x, E.x); E.y = __builtin_fmaf(c.bs.y, c.w.y, E.y); E.z = __builtin_fmaf(c.bs.z, c.w.z, E.z);
                 };
                 u32 k = 0;
                 for (; k + 4 <= nk; k += 4) {
-                    f3 c0 = term(k), c1 = term(k + 1), c2 = term(k + 2), c3 = term(k + 3);
-                    E = E + c0; E = E + c1; E = E + c2; E = E + c3;
+                    Term c0 = term(k), c1 = term(k + 1), c2 = term(k + 2), c3 = term(k + 3);
+                    add(c0); add(c1); add(c2); add(c3);
                 }
-                for (; k < nk; k++) E = E + term(k);
+                for (; k < nk; k++) add(term(k));
             };
             if (MODE == 0 && grey) run(std::true_type()); else run(std::false_type());
             pairs += nk;
