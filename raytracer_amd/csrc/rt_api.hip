@@ -81,7 +81,7 @@ struct rt_ctx {
     // path buffers
     u32 n_paths = 0; float* d_arena = nullptr;
     RayQueue q[2]; HitBuf hits; PathState ps; SlotState st[2]; GatherQueue gq; int* d_stack_spill = nullptr;
-    u32* d_task_counter = nullptr; u32 persistent_slots = 0; int persistent = -1; // RT_PERSISTENT: -1 by scene (default), 0 never, bit 0 queued launches, bit 1 primary launches
+    u32* d_task_counter = nullptr; u32 persistent_slots = 0; int persistent = 0; // RT_PERSISTENT: 0 never (default), bit 0 queued launches, bit 1 primary launches
     int wave_major = 1; // RT_WAVE_MAJOR
     int ray_sort = 1; // RT_RAY_SORT: group the surviving rays of a bounce by direction octant (fused camera pass)
     u32* d_seg_count = nullptr; u32 n_segments_cap = 0; DeviceStats* d_stats = nullptr;
@@ -162,9 +162,9 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.ray_sort = c->ray_sort ? 1u : 0u;
     a.wave_major = c->wave_major ? 1u : 0u;
     a.task_counter = c->d_task_counter; a.persistent_slots = c->persistent_slots;
-    // persistent traversal waves pay ~2.5 us per 64-ray task and win back the dispatcher's idle slots: worth it when tasks
-    // are long, i.e. when rays walk a deep top level before they reach a mesh (k_traverse, rt_kernels.hip)
-    a.persistent = c->persistent >= 0 ? (u32) c->persistent : (c->n_instances >= 1024u ? 1u : 0u);
+    // persistent traversal waves pay ~2.5 us per 64-ray task and win back the dispatcher's idle slots; since the dispatched
+    // kernels run 6 waves per SIMD in wave-major order that no longer pays on any benchmark scene (k_traverse, rt_kernels.hip)
+    a.persistent = c->persistent > 0 ? (u32) c->persistent : 0u;
     a.st[0] = c->st[0]; a.st[1] = c->st[1];
     for (int k = 0; k < 3; k++) a.camera_origin[k] = c->g.camera_to_world[12 + k] / c->g.camera_to_world[15];
     a.fudge = (c->flags & RT_FLAG_ENABLE_SSS) ? c->g.translucent_bssrdf_fudge : 0.0f;

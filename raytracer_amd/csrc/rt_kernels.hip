@@ -242,9 +242,10 @@ RT_DEV void traverse_counters_flush(const PassArgs& a, const TraverseCounters& c
 // has to place tens of thousands of one-wave workgroups whose lifetimes range from 4 us (the empty waves behind the
 // compacted part of a segment) to ~90 us (timeline from per-wave timestamps); persistent waves
 // keep 90 % occupied and balance the end of the launch by themselves.  The price is one device-scope atomic round trip
-// per task (~2.5 us under load, exposed: memory operations return in order), so this pays when tasks are long: +24 %
-// on the 52,743-instance field (tasks of ~100 us), -10 % on the bunny (24 us), -34 % on the Cornell box (5 us).
-// rt_api.hip picks the mode per scene.
+// per task (~2.5 us under load, exposed: memory operations return in order) and one wave per SIMD less (96 VGPRs).  It
+// was worth +24 % on the 52,743-instance field (tasks of ~100 us) while the dispatched kernels ran 5 waves per SIMD in
+// segment order; against today's dispatched kernels (6 waves, wave-major task order) it loses everywhere: -7 % on the
+// field at 4K, -14 % at 1080p, -19 % on the bunny.  So it is off by default and kept as an option (RT_PERSISTENT).
 // The tasks (waves of 64 queue slots) are dealt to TASK_PARTS interleaved partitions, each with its own counter in its
 // own cache line: atomics on ONE address run at ~90 per microsecond on MI355X, which would make the 32,640 tasks of a
 // 1080p launch cost 0.36 ms.  A wave works through its home partition, then moves to the one with the most tasks left.

@@ -40,7 +40,7 @@ def test_c3_cornell_1080p_every_ray(oracle_mod):
 def test_persistent_and_dispatched_traversal_agree_with_the_oracle(oracle_mod, monkeypatch, mode):
     """k_traverse has two ways of handing 64-ray tasks to waves: one workgroup per task (RT_PERSISTENT=0), or one
     persistent wave per slot that takes tasks from partitioned counters with stealing (bit 0: queued launches, bit 1:
-    primary launches); the library picks by scene.  Both are forced here on a frame large enough for the persistent
+    primary launches; off by default).  Both are forced here on a frame large enough for the persistent
     grid (more than 5,120 tasks), with ray grouping on, and compared ray by ray; two frames, so that the counters are
     seen to be left at zero by the first."""
     monkeypatch.setenv("RT_PERSISTENT", mode)
