@@ -85,6 +85,19 @@ struct rt_ctx {
     int wave_major = 1; // RT_WAVE_MAJOR
     int ray_sort = 1; // RT_RAY_SORT: group the surviving rays of a bounce by direction octant (fused camera pass)
     u32* d_seg_count = nullptr; u32 n_segments_cap = 0; DeviceStats* d_stats = nullptr;
+    // frames in flight: consecutive camera-only dispatches alternate between two lanes (a stream and a set of path buffers
+    // each), so that the HBM-bound shade kernels of one frame run beside the issue-bound traversal of the other and the
+    // tails of the launches are filled; the fused shades then leave the pixels' sample sums in ps.sum_* and one small
+    // kernel per frame (k_frame_resolve), which waits for the frame before, adds them to the accumulator (run_pass).
+    // Lane 0 is `stream` and the members above; lane 1's stream and buffers sit here and are swapped in for the
+    // duration of its dispatch.
+    struct PathBuffers { float* d_arena; u32* d_seg_count; RayQueue q[2]; HitBuf hits; PathState ps; SlotState st[2]; GatherQueue gq; int* d_stack_spill; };
+    PathBuffers alt; hipStream_t alt_stream = nullptr; hipEvent_t lane_done[2] = { nullptr, nullptr };
+    int frames_in_flight = 2;              // RT_FRAMES_IN_FLIGHT: 1 = every dispatch on `stream`, in order
+    bool pipelined = false;                // the calls since the last quiesce() were pipelined dispatches: lane 1 may hold work
+    int next_lane = 0; bool have_previous = false;
+    hipEvent_t accumulate_after = nullptr; // run_pass: the frame's resolve waits for this (the previous frame's end)
+    bool defer_resolve = false;            // run_pass: pipelined frame (k_frame_resolve instead of the resolve inside k_shade)
     // BSSRDF tables
     float* d_table[2] = { nullptr, nullptr }; int table_texels[2] = { 0, 0 }; int profile = 0;
     // stats
@@ -92,7 +105,7 @@ struct rt_ctx {
     uint64_t traverse_launches = 0, gather_launches = 0, primary_rays = 0, traverse_launches_timed = 0, gather_launches_timed = 0;
     uint64_t dispatch_index = 0; // rt_dispatch_rays calls so far (RT_FLAG_TIME_SAMPLED times every 8th)
     double blas_build_ms = 0, tlas_build_ms = 0; uint64_t blas_triangles = 0;
-    rt_ctx() { memset(&g, 0, sizeof g); memset(q, 0, sizeof q); memset(&hits, 0, sizeof hits); memset(&ps, 0, sizeof ps); memset(st, 0, sizeof st); memset(&gq, 0, sizeof gq); }
+    rt_ctx() { memset(&g, 0, sizeof g); memset(q, 0, sizeof q); memset(&hits, 0, sizeof hits); memset(&ps, 0, sizeof ps); memset(st, 0, sizeof st); memset(&gq, 0, sizeof gq); memset(&alt, 0, sizeof alt); }
 };
 
 namespace {
@@ -112,16 +125,18 @@ void invert_affine(const float* m, float* inv) {
     for (int j = 0; j < 3; j++) inv[9 + j] = (float) it[j];
 }
 
-int ensure_path_buffers(rt_ctx* c) {
-    u32 tiles = ((c->width + 31) / 32) * ((c->height + 31) / 32);
-    u32 segs = std::max(tiles, (c->n_points + 1023) / 1024);
-    if (segs == 0) segs = 1;
+void swap_path_buffers(rt_ctx* c) {
+    rt_ctx::PathBuffers& o = c->alt;
+    std::swap(c->d_arena, o.d_arena); std::swap(c->d_seg_count, o.d_seg_count); std::swap(c->hits, o.hits); std::swap(c->ps, o.ps);
+    std::swap(c->gq, o.gq); std::swap(c->d_stack_spill, o.d_stack_spill);
+    for (int k = 0; k < 2; k++) { std::swap(c->q[k], o.q[k]); std::swap(c->st[k], o.st[k]); }
+}
+
+// allocates the current set of path buffers for `segs` segments of 1024 queue slots
+int alloc_path_buffers(rt_ctx* c, u32 segs) {
     u32 need = segs * 1024; // queue slots; path-state arrays are indexed by pixel / point id < need
-    if (need <= c->n_paths) return RT_OK;
-    dev_free(c->d_arena); dev_free(c->d_seg_count);
     RT_HIP(hipMalloc(&c->d_seg_count, sizeof(u32) * (4 * (size_t) segs + 1))); // 2 queues, gather, gather offsets
     RT_HIP(hipMemset(c->d_seg_count, 0, sizeof(u32) * (4 * (size_t) segs + 1)));
-    c->n_segments_cap = segs;
     const int n_arrays = 14 /* 2 queues x (6 + path) */ + 5 /* hits */ + 15 /* path state */ + 14 /* slot state x 2 */ + 9 /* gather */ + 48 /* stack spill */;
     size_t stride = ((size_t) need + 63) & ~(size_t) 63;
     RT_HIP(hipMalloc(&c->d_arena, stride * 4 * n_arrays));
@@ -144,7 +159,42 @@ int ensure_path_buffers(rt_ctx* c) {
     c->gq.path = (u32*) take(); c->gq.hx = take(); c->gq.hy = take(); c->gq.hz = take(); c->gq.tf = take();
     c->gq.kx = take(); c->gq.ky = take(); c->gq.kz = take(); c->gq.ti = (int*) take();
     c->d_stack_spill = (int*) p; p += 48 * stride;
-    c->n_paths = (u32) stride;
+    c->n_paths = (u32) stride; c->n_segments_cap = segs;
+    return RT_OK;
+}
+
+// callers have quiesced the context: nothing is in flight on either lane
+int ensure_path_buffers(rt_ctx* c) {
+    u32 tiles = ((c->width + 31) / 32) * ((c->height + 31) / 32);
+    u32 segs = std::max(tiles, (c->n_points + 1023) / 1024);
+    if (segs == 0) segs = 1;
+    if (segs * 1024 <= c->n_paths) return RT_OK;
+    dev_free(c->d_arena); dev_free(c->d_seg_count);
+    dev_free(c->alt.d_arena); dev_free(c->alt.d_seg_count); // lane 1's set is allocated again, at the new size, when a dispatch first needs it
+    memset(&c->alt, 0, sizeof c->alt);
+    c->n_paths = 0;
+    return alloc_path_buffers(c, segs);
+}
+
+// lane 1 of the frame pipeline: its stream, its buffers, the two end-of-frame events
+int ensure_second_lane(rt_ctx* c) {
+    if (!c->alt_stream) RT_HIP(hipStreamCreateWithFlags(&c->alt_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) if (!c->lane_done[k]) RT_HIP(hipEventCreateWithFlags(&c->lane_done[k], hipEventDisableTiming));
+    if (c->alt.d_arena) return RT_OK;
+    swap_path_buffers(c);
+    int rc = alloc_path_buffers(c, c->n_segments_cap);
+    swap_path_buffers(c);
+    return rc;
+}
+
+// every entry point other than a pipelined dispatch starts here: lane 1 drained, so that work on `stream` is ordered
+// after everything before it as it would be with one stream
+int quiesce(rt_ctx* c) {
+    if (c->pipelined) {
+        c->pipelined = false;
+        RT_HIP(hipStreamSynchronize(c->alt_stream));
+        RT_HIP(hipStreamSynchronize(c->own_stream));
+    }
     return RT_OK;
 }
 
@@ -282,6 +332,7 @@ int run_pass(rt_ctx* c, bool probe) {
     // camera pass: no ray-generation kernel (bounce 0 derives rays from pixels), and unless the gather kernel can add
     // emission after a path's last shade, no resolve kernel either (finished paths resolve their pixel in k_shade)
     bool fused = !probe && !gather;
+    a.defer_resolve = c->defer_resolve ? 1u : 0u;
     for (u32 s = 0; s < c->g.samples_per_pixel; s++) {
         int rc = RT_OK;
         if (probe) { rc = launch_probe_raygen(c->stream, a, s); if (rc) return rc; }
@@ -293,6 +344,12 @@ int run_pass(rt_ctx* c, bool probe) {
         }
     }
     if (probe) return launch_probe_resolve(c->stream, a);
+    if (c->defer_resolve) {
+        // pipelined frames: pixels are added to in frame order, by this kernel alone; all the tracing and shading above
+        // overlaps the frame before
+        if (c->accumulate_after) RT_HIP(hipStreamWaitEvent(c->stream, c->accumulate_after, 0));
+        return launch_frame_resolve(c->stream, a);
+    }
     return fused ? RT_OK : launch_camera_resolve(c->stream, a);
 }
 
@@ -337,6 +394,7 @@ int rt_create(const int* devices, int n, rt_ctx** out) {
     if (const char* v = getenv("RT_RAY_SORT")) c->ray_sort = atoi(v);
     if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
     if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
+    if (const char* v = getenv("RT_FRAMES_IN_FLIGHT")) c->frames_in_flight = atoi(v);
     {
         hipDeviceProp_t prop;
         RT_HIP(hipGetDeviceProperties(&prop, c->device));
@@ -356,8 +414,12 @@ int rt_create(const int* devices, int n, rt_ctx** out) {
 void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void) hipSetDevice(c->device);
+    (void) quiesce(c);
     (void) hipStreamSynchronize(c->stream);
     drain_timers(c);
+    dev_free(c->alt.d_arena); dev_free(c->alt.d_seg_count);
+    if (c->alt_stream) (void) hipStreamDestroy(c->alt_stream);
+    for (int k = 0; k < 2; k++) if (c->lane_done[k]) (void) hipEventDestroy(c->lane_done[k]);
     for (auto& b : c->blas) {
         dev_free(b.d_verts); dev_free(b.d_indices); dev_free(b.d_geoms); dev_free(b.d_tri_geometry);
         dev_free(b.d_nodes); b.d_tris = nullptr; dev_free(b.d_perm);
@@ -375,6 +437,7 @@ void rt_destroy(rt_ctx* c) {
 
 int rt_set_stream(rt_ctx* c, void* s) {
     if (!c) return RT_ERR_INVALID;
+    { int rc = quiesce(c); if (rc) return rc; }
     RT_HIP(hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t) s : c->own_stream;
     return RT_OK;
@@ -383,6 +446,7 @@ int rt_set_stream(rt_ctx* c, void* s) {
 int rt_update_resolution(rt_ctx* c, uint32_t w, uint32_t h) {
     if (!c || w == 0 || h == 0 || (uint64_t) w * h > (1ull << 28)) { set_error("rt_update_resolution: bad size"); return RT_ERR_INVALID; }
     RT_HIP(hipSetDevice(c->device));
+    { int rc = quiesce(c); if (rc) return rc; }
     RT_HIP(hipStreamSynchronize(c->stream));
     dev_free(c->d_accumulator); dev_free(c->d_render_target);
     c->width = w; c->height = h;
@@ -395,6 +459,7 @@ int rt_update_resolution(rt_ctx* c, uint32_t w, uint32_t h) {
 
 int rt_load_bssrdf_table(rt_ctx* c, int profile, const float* r, const float* g, const float* b, uint32_t n) {
     if (!c || profile < 0 || profile > 1 || !r || !g || !b || n == 0) { set_error("rt_load_bssrdf_table: bad arguments"); return RT_ERR_INVALID; }
+    { int qrc = quiesce(c); if (qrc) return qrc; }
     RT_HIP(hipSetDevice(c->device));
     u32 padded = ((n + 255u) / 256u) * 256u; // raytracing.cpp:113
     std::vector<float> t((size_t) padded * 3, 0.0f);
@@ -415,6 +480,7 @@ int rt_set_bssrdf_profile(rt_ctx* c, int profile) {
 
 int rt_build_blas(rt_ctx* c, const RtGeometry* geometries, int n, rt_blas* out) {
     if (!c || !geometries || n < 1 || !out) { set_error("rt_build_blas: bad arguments"); return RT_ERR_INVALID; }
+    { int qrc = quiesce(c); if (qrc) return qrc; }
     RT_HIP(hipSetDevice(c->device));
     Blas b;
     b.translucent_ids_index = (u32) c->translucent_mean_area.size();
@@ -504,6 +570,7 @@ int rt_build_blas(rt_ctx* c, const RtGeometry* geometries, int n, rt_blas* out) 
 
 int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
     if (!c || !instances || n < 1) { set_error("rt_build_tlas: bad arguments"); return RT_ERR_INVALID; }
+    { int qrc = quiesce(c); if (qrc) return qrc; }
     RT_HIP(hipSetDevice(c->device));
     for (int i = 0; i < n; i++)
         if (instances[i].blas < 0 || instances[i].blas >= (int) c->blas.size()) { set_error("rt_build_tlas: instance %d has a bad BLAS handle", i); return RT_ERR_INVALID; }
@@ -574,6 +641,7 @@ namespace { int hg_build_all(rt_ctx* c); } // hierarchical gather trees, defined
 
 int rt_generate_translucent_samples(rt_ctx* c, float radius, uint32_t rng_seed, uint32_t phase_seed, uint32_t* total) {
     if (!c || !total || !(radius > 0.0f)) { set_error("rt_generate_translucent_samples: bad arguments"); return RT_ERR_INVALID; }
+    { int qrc = quiesce(c); if (qrc) return qrc; }
     *total = 0;
     if (c->n_instances == 0) { set_error("rt_generate_translucent_samples: call rt_build_tlas first"); return RT_ERR_STATE; }
     if (c->g.translucent_instance_stride == 0) return RT_OK; // raytracing.cpp:554
@@ -798,8 +866,36 @@ int rt_dispatch_rays(rt_ctx* c) {
         set_error("rt_dispatch_rays: tabulated BSSRDF selected but profile %d was never loaded", c->profile); return RT_ERR_STATE;
     }
     RT_HIP(hipSetDevice(c->device));
-    int rc = ensure_path_buffers(c); if (rc) return rc;
     bool collect = (c->flags & RT_FLAG_COLLECT_SAMPLES) && c->n_points > 0;
+    const bool gather = c->n_points > 0 && (c->flags & RT_FLAG_ENABLE_SSS) && c->g.translucent_bssrdf_fudge != 0.0f;
+    // a camera-only frame without the gather kernel touches nothing outside its path buffers but the accumulator and the
+    // render target: such frames are pipelined over the two lanes
+    if (c->frames_in_flight > 1 && c->stream == c->own_stream && !collect && !gather && c->persistent <= 0 &&
+        !(c->flags & (RT_FLAG_DOUBLE_DISPATCH | RT_FLAG_CAPTURE_HITS | RT_FLAG_COUNT_TRAVERSAL))) {
+        if (!c->pipelined) { // everything enqueued so far is finished before lane 1 starts beside it
+            RT_HIP(hipStreamSynchronize(c->stream));
+            int rc = ensure_path_buffers(c); if (rc) return rc;
+            rc = ensure_second_lane(c); if (rc) return rc;
+            c->pipelined = true; c->next_lane = 0; c->have_previous = false;
+        }
+        const int lane = c->next_lane;
+        if (lane) { swap_path_buffers(c); std::swap(c->stream, c->alt_stream); }
+        c->accumulate_after = c->have_previous ? c->lane_done[lane ^ 1] : nullptr;
+        c->defer_resolve = true;
+        int rc = run_pass(c, false);
+        c->defer_resolve = false;
+        if (rc == RT_OK && hipEventRecord(c->lane_done[lane], c->stream) != hipSuccess) { set_error("rt_dispatch_rays: event record failed"); rc = RT_ERR_DEVICE; }
+        c->accumulate_after = nullptr;
+        if (lane) { swap_path_buffers(c); std::swap(c->stream, c->alt_stream); }
+        if (rc) return rc;
+        c->next_lane ^= 1; c->have_previous = true;
+        c->dispatch_index++;
+        c->g.accumulator_count += 1;                                                  // :744
+        c->g.translucent_accumulator_count += (c->flags & RT_FLAG_COLLECT_SAMPLES) ? 1u : 0u; // :745
+        return RT_OK;
+    }
+    int rc = quiesce(c); if (rc) return rc;
+    rc = ensure_path_buffers(c); if (rc) return rc;
     auto refresh_hg = [&]() -> int { // node sums of the payloads the camera pass is about to read
         if (!(c->hg_enabled && c->hg_built)) return RT_OK;
         PassArgs a; fill_pass_args(c, a, false);
@@ -819,24 +915,28 @@ int rt_dispatch_rays(rt_ctx* c) {
 
 int rt_sync(rt_ctx* c) {
     if (!c) return RT_ERR_INVALID;
+    { int rc = quiesce(c); if (rc) return rc; }
     RT_HIP(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 
 int rt_read_accumulator(rt_ctx* c, float* rgba) {
     if (!c || !rgba || !c->d_accumulator) return RT_ERR_INVALID;
+    { int qrc = quiesce(c); if (qrc) return qrc; }
     RT_HIP(hipMemcpyAsync(rgba, c->d_accumulator, (size_t) c->width * c->height * 16, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 int rt_read_render_target(rt_ctx* c, uint8_t* rgba8) {
     if (!c || !rgba8 || !c->d_render_target) return RT_ERR_INVALID;
+    { int qrc = quiesce(c); if (qrc) return qrc; }
     RT_HIP(hipMemcpyAsync(rgba8, c->d_render_target, (size_t) c->width * c->height * 4, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 int rt_read_hit_records(rt_ctx* c, uint32_t bounce, RtHit* out) {
     if (!c || !out || !c->d_capture || bounce >= c->capture_bounces) { set_error("rt_read_hit_records: nothing captured for bounce %u", bounce); return RT_ERR_INVALID; }
+    { int qrc = quiesce(c); if (qrc) return qrc; }
     size_t n = (size_t) c->width * c->height;
     RT_HIP(hipMemcpyAsync(out, c->d_capture + bounce * n, n * sizeof(RtHit), hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
@@ -849,6 +949,7 @@ int rt_sample_point_count(rt_ctx* c, uint32_t instance, uint32_t* n) {
 }
 int rt_read_sample_points(rt_ctx* c, uint32_t instance, RtSamplePoint* points, float* normals) {
     if (!c || instance >= c->slices.size()) return RT_ERR_INVALID;
+    { int qrc = quiesce(c); if (qrc) return qrc; }
     const TranslucentSlice& sl = c->slices[instance];
     if (points) RT_HIP(hipMemcpyAsync(points, c->d_sp_read + sl.offset, sizeof(RtSamplePoint) * sl.count, hipMemcpyDeviceToHost, c->stream));
     if (normals) RT_HIP(hipMemcpyAsync(normals, c->d_sp_normal + 3 * (size_t) sl.offset, 12 * (size_t) sl.count, hipMemcpyDeviceToHost, c->stream));
@@ -858,6 +959,7 @@ int rt_read_sample_points(rt_ctx* c, uint32_t instance, RtSamplePoint* points, f
 
 int rt_get_stats(rt_ctx* c, RtStats* out) {
     if (!c || !out) return RT_ERR_INVALID;
+    { int qrc = quiesce(c); if (qrc) return qrc; }
     RT_HIP(hipStreamSynchronize(c->stream));
     int rc = drain_timers(c); if (rc) return rc;
     DeviceStats ds;
@@ -875,6 +977,7 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
 }
 int rt_reset_stats(rt_ctx* c) {
     if (!c) return RT_ERR_INVALID;
+    { int qrc = quiesce(c); if (qrc) return qrc; }
     RT_HIP(hipStreamSynchronize(c->stream));
     int rc = drain_timers(c); if (rc) return rc;
     RT_HIP(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
@@ -885,12 +988,14 @@ int rt_reset_stats(rt_ctx* c) {
 
 int rt_accumulator_device_ptr(rt_ctx* c, void** dev_ptr, size_t* bytes) {
     if (!c || !dev_ptr || !bytes || !c->d_accumulator) return RT_ERR_INVALID;
+    { int qrc = quiesce(c); if (qrc) return qrc; }
     *dev_ptr = c->d_accumulator; *bytes = (size_t) c->width * c->height * 16;
     return RT_OK;
 }
 
 int rt_resolve_render_target(rt_ctx* c) {
     if (!c || !c->d_accumulator) return RT_ERR_INVALID;
+    { int qrc = quiesce(c); if (qrc) return qrc; }
     PassArgs a; fill_pass_args(c, a, false);
     return launch_resolve_only(c->stream, a);
 }

@@ -130,6 +130,7 @@ struct PassArgs {
     u32* task_counter;           // persistent traversal: 64 task counters + 1 done counter, 128 bytes apart; all zero between launches
     u32 persistent_slots;        // wave slots of the device for the traversal kernel (CUs x 4 SIMDs x 5 waves), 0 = never persistent
     u32 persistent;              // bit 0: queued (secondary / probe) launches persistent, bit 1: primary launches too
+    u32 defer_resolve;           // fused camera pass: finished paths leave their pixel's sample sum in ps.sum_* for k_frame_resolve
     u32 wave_major;              // queued traverse launches: task -> (segment, wave) mapping, see k_traverse (RT_WAVE_MAJOR)
     u32 ray_sort;                // fused camera pass: survivors of a bounce are grouped by direction octant inside their segment (RT_RAY_SORT)
     SlotState st[2];             // fused camera pass: path state by queue slot
@@ -175,6 +176,7 @@ int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32
 int launch_gather(hipStream_t s, const PassArgs& a);
 int launch_hg_sums(hipStream_t s, const PassArgs& a, u32 n_slices); // refresh HgView::pay / sums from sp_read
 int launch_camera_resolve(hipStream_t s, const PassArgs& a);
+int launch_frame_resolve(hipStream_t s, const PassArgs& a); // pipelined frames: adds the sample sums the fused shades left in ps.sum_* (a.defer_resolve)
 int launch_probe_resolve(hipStream_t s, const PassArgs& a);
 int launch_fill_capture(hipStream_t s, const PassArgs& a);
 int launch_resolve_only(hipStream_t s, const PassArgs& a); // raytracing.hlsl:161 after an external accumulator sum

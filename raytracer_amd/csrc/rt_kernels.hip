@@ -148,6 +148,18 @@ __global__ __launch_bounds__(BT) void k_camera_resolve(PassArgs a) {
     resolve_pixel(a, pixel, tot);
 }
 
+// pipelined frames (a.defer_resolve): the fused shades leave each pixel's sample sum in ps.sum_* and this kernel, the only
+// one of the frame that touches the accumulator, adds it in -- the frames' resolves run in frame order, everything else
+// of a frame overlaps its neighbours.  Same additions in the same order as the resolve inside k_shade.
+__global__ __launch_bounds__(BT) void k_frame_resolve(PassArgs a) {
+    u32 t = blockIdx.x * BT + threadIdx.x;
+    u32 px, py;
+    if (!thread_pixel(a, t, px, py)) return;
+    u32 pixel = py * a.width + px;
+    float tot[4] = { a.ps.sum_x[pixel], a.ps.sum_y[pixel], a.ps.sum_z[pixel], a.ps.sum_a[pixel] };
+    resolve_pixel(a, pixel, tot);
+}
+
 // re-derives the render target from an accumulator that already holds `accumulator_count` frames
 __global__ __launch_bounds__(BT) void k_resolve_only(PassArgs a) {
     u32 pixel = blockIdx.x * BT + threadIdx.x;
@@ -409,7 +421,8 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             if (sample_index + 1u < a.g.samples_per_pixel) {
                 a.ps.rng[path] = rng; // the next sample of this pixel continues the stream (raytracing.hlsl:130,141)
                 for (int k = 0; k < 4; k++) sum[k][path] = tot[k];
-            } else resolve_pixel(a, path, tot);
+            } else if (a.defer_resolve) { for (int k = 0; k < 4; k++) sum[k][path] = tot[k]; } // k_frame_resolve adds it in
+            else resolve_pixel(a, path, tot);
         }
         if (alive) { no = o + r.t * d; nd = r.scatter; }       // :118-119
         if (a.probe && !cont) {
@@ -849,6 +862,13 @@ int launch_camera_resolve(hipStream_t s, const PassArgs& a) {
     size_t threads = (size_t) a.n_local_tiles * 1024;
     if (!threads) return RT_OK;
     hipLaunchKernelGGL(k_camera_resolve, blocks(threads, BT), dim3(BT), 0, s, a);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+int launch_frame_resolve(hipStream_t s, const PassArgs& a) {
+    size_t threads = (size_t) a.n_local_tiles * 1024;
+    if (!threads) return RT_OK;
+    hipLaunchKernelGGL(k_frame_resolve, blocks(threads, BT), dim3(BT), 0, s, a);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

@@ -74,3 +74,33 @@ def test_c5_instanced_field_4k_every_ray(oracle_mod):
     scene = scenes.bunny_field(3840, 2160, spp=1, bounces=4)
     assert scene.triangle_count() > 49000000
     assert _full_parity(scene, oracle_mod, frames=1) > 20000000
+
+
+def test_frames_in_flight_do_not_change_the_image(monkeypatch):
+    """Camera-only dispatches are pipelined over two streams with two sets of path buffers (RT_FRAMES_IN_FLIGHT,
+    default 2); only the accumulating shades wait for the frame before.  Same bits as one frame at a time, for one and
+    for several samples per pixel, with a tile split, and across a read in the middle of the sequence (which drains the
+    pipeline and starts it again)."""
+    from raytracer_amd import api, distributed
+    cases = [(scenes.bunny(1280, 720, spp=1, bounces=2), None), (scenes.cornell(640, 360, spp=3, bounces=3), None),
+             (scenes.bunny(1920, 1080, spp=1, bounces=1), (1, 2))]
+    results = {}
+    for fif in ("1", "2"):
+        monkeypatch.setenv("RT_FRAMES_IN_FLIGHT", fif)
+        for k, (scene, split) in enumerate(cases):
+            rt = api.Raytracer(0)
+            try:
+                scene.setup(rt)
+                if split: rt.set_tile_split(*split)
+                mid = None
+                for f in range(9):
+                    distributed.render_frame(rt, scene.globals, f, 23)
+                    if f == 4: mid = rt.read_render_target()
+                results[(fif, k)] = (rt.read_accumulator(), rt.read_render_target(), mid)
+            finally:
+                rt.close()
+    for k in range(len(cases)):
+        a, b = results[("1", k)], results[("2", k)]
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert a[0].any()
