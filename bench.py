@@ -229,8 +229,8 @@ def main():
             "config": {"workload": label, "width": args.width, "height": args.height, "triangles": scene.triangle_count(),
                        "sample_points": points, "rays_per_step_per_gpu": rays / args.steps,
                        "parallelism": "sample-set split x%d + RCCL reduce" % world if world > 1 else "single GPU",
-                       # camera-only steps overlap pairwise on the GPU (the library's default; scenes with the BSSRDF gather run one at a time)
-                       "frames_in_flight": 1 if points else max(1, min(2, int(os.environ.get("RT_FRAMES_IN_FLIGHT", "2"))))},
+                       # consecutive steps overlap pairwise on the GPU (the library's default, RT_FRAMES_IN_FLIGHT)
+                       "frames_in_flight": 1 if args.hg is not None else max(1, min(2, int(os.environ.get("RT_FRAMES_IN_FLIGHT", "2"))))},
             "roofline": {"bound": "hbm", "kernel": "k_traverse", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_trav * rays_per_launch,

@@ -96,6 +96,11 @@ struct rt_ctx {
     int frames_in_flight = 2;              // RT_FRAMES_IN_FLIGHT: 1 = every dispatch on `stream`, in order
     bool pipelined = false;                // the calls since the last quiesce() were pipelined dispatches: lane 1 may hold work
     int next_lane = 0; bool have_previous = false;
+    // frames with the sample-point pass or the gather are pipelined too: each lane gathers from its own copy of the sample
+    // points (d_sp_read / d_sp_read_alt), the passes that update d_sp_write and the copies out of it run in frame order
+    // (probe_done), the rest of a frame beside the frame before.  sp_version counts the updates of d_sp_write.
+    RtSamplePoint* d_sp_read_alt = nullptr; hipEvent_t probe_done[2] = { nullptr, nullptr }; int last_probe_lane = -1;
+    uint64_t sp_version = 0, sp_read_version[2] = { 0, 0 };
     hipEvent_t accumulate_after = nullptr; // run_pass: the frame's resolve waits for this (the previous frame's end)
     bool defer_resolve = false;            // run_pass: pipelined frame (k_frame_resolve instead of the resolve inside k_shade)
     // BSSRDF tables
@@ -180,6 +185,11 @@ int ensure_path_buffers(rt_ctx* c) {
 int ensure_second_lane(rt_ctx* c) {
     if (!c->alt_stream) RT_HIP(hipStreamCreateWithFlags(&c->alt_stream, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) if (!c->lane_done[k]) RT_HIP(hipEventCreateWithFlags(&c->lane_done[k], hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) if (!c->probe_done[k]) RT_HIP(hipEventCreateWithFlags(&c->probe_done[k], hipEventDisableTiming));
+    if (c->n_points && !c->d_sp_read_alt) {
+        RT_HIP(hipMalloc(&c->d_sp_read_alt, sizeof(RtSamplePoint) * c->n_points));
+        c->sp_read_version[1] = ~0ull; // filled from d_sp_write by the first frame that gathers from it
+    }
     if (c->alt.d_arena) return RT_OK;
     swap_path_buffers(c);
     int rc = alloc_path_buffers(c, c->n_segments_cap);
@@ -200,6 +210,7 @@ int quiesce(rt_ctx* c) {
 
 void free_sample_points(rt_ctx* c) {
     dev_free(c->d_sp_read); dev_free(c->d_sp_write); dev_free(c->d_sp_normal); dev_free(c->d_sp_slice);
+    dev_free(c->d_sp_read_alt); c->sp_version = 0; c->sp_read_version[0] = 0; c->sp_read_version[1] = ~0ull;
     dev_free(c->d_slices); dev_free(c->d_slot_to_ti);
     dev_free(c->d_hg_nodes); dev_free(c->d_hg_sums); dev_free(c->d_hg_pos); dev_free(c->d_hg_pay); dev_free(c->d_hg_order); dev_free(c->d_hg_slices);
     c->hg_built = false;
@@ -332,7 +343,7 @@ int run_pass(rt_ctx* c, bool probe) {
     // camera pass: no ray-generation kernel (bounce 0 derives rays from pixels), and unless the gather kernel can add
     // emission after a path's last shade, no resolve kernel either (finished paths resolve their pixel in k_shade)
     bool fused = !probe && !gather;
-    a.defer_resolve = c->defer_resolve ? 1u : 0u;
+    a.defer_resolve = (c->defer_resolve && fused) ? 1u : 0u;
     for (u32 s = 0; s < c->g.samples_per_pixel; s++) {
         int rc = RT_OK;
         if (probe) { rc = launch_probe_raygen(c->stream, a, s); if (rc) return rc; }
@@ -344,13 +355,11 @@ int run_pass(rt_ctx* c, bool probe) {
         }
     }
     if (probe) return launch_probe_resolve(c->stream, a);
-    if (c->defer_resolve) {
-        // pipelined frames: pixels are added to in frame order, by this kernel alone; all the tracing and shading above
-        // overlaps the frame before
-        if (c->accumulate_after) RT_HIP(hipStreamWaitEvent(c->stream, c->accumulate_after, 0));
-        return launch_frame_resolve(c->stream, a);
-    }
-    return fused ? RT_OK : launch_camera_resolve(c->stream, a);
+    if (fused && !c->defer_resolve) return RT_OK;
+    // pipelined frames: pixels are added to in frame order, by the frame's resolve kernel alone; all the tracing, shading
+    // and gathering above overlaps the frame before
+    if (c->accumulate_after) RT_HIP(hipStreamWaitEvent(c->stream, c->accumulate_after, 0));
+    return fused ? launch_frame_resolve(c->stream, a) : launch_camera_resolve(c->stream, a);
 }
 
 float triangle_area(const float* a, const float* b, const float* c) { // geometry.cpp:21-25
@@ -420,6 +429,7 @@ void rt_destroy(rt_ctx* c) {
     dev_free(c->alt.d_arena); dev_free(c->alt.d_seg_count);
     if (c->alt_stream) (void) hipStreamDestroy(c->alt_stream);
     for (int k = 0; k < 2; k++) if (c->lane_done[k]) (void) hipEventDestroy(c->lane_done[k]);
+    for (int k = 0; k < 2; k++) if (c->probe_done[k]) (void) hipEventDestroy(c->probe_done[k]);
     for (auto& b : c->blas) {
         dev_free(b.d_verts); dev_free(b.d_indices); dev_free(b.d_geoms); dev_free(b.d_tri_geometry);
         dev_free(b.d_nodes); b.d_tris = nullptr; dev_free(b.d_perm);
@@ -868,25 +878,38 @@ int rt_dispatch_rays(rt_ctx* c) {
     RT_HIP(hipSetDevice(c->device));
     bool collect = (c->flags & RT_FLAG_COLLECT_SAMPLES) && c->n_points > 0;
     const bool gather = c->n_points > 0 && (c->flags & RT_FLAG_ENABLE_SSS) && c->g.translucent_bssrdf_fudge != 0.0f;
-    // a camera-only frame without the gather kernel touches nothing outside its path buffers but the accumulator and the
-    // render target: such frames are pipelined over the two lanes
-    if (c->frames_in_flight > 1 && c->stream == c->own_stream && !collect && !gather && c->persistent <= 0 &&
+    // Frames are pipelined over the two lanes.  A frame touches its lane's path buffers and copy of the sample points,
+    // and three things it shares with its neighbours, each in frame order: the accumulator and the render target (the
+    // frame's resolve kernel, after the resolve of the frame before: run_pass), and d_sp_write (the sample-point pass
+    // and the copy out of it, after those of the frame before: probe_done).
+    const bool hierarchical = c->hg_enabled && c->hg_built && c->n_points > 0; // node sums are shared state: one frame at a time
+    if (c->frames_in_flight > 1 && c->stream == c->own_stream && !hierarchical && c->persistent <= 0 &&
         !(c->flags & (RT_FLAG_DOUBLE_DISPATCH | RT_FLAG_CAPTURE_HITS | RT_FLAG_COUNT_TRAVERSAL))) {
         if (!c->pipelined) { // everything enqueued so far is finished before lane 1 starts beside it
             RT_HIP(hipStreamSynchronize(c->stream));
             int rc = ensure_path_buffers(c); if (rc) return rc;
             rc = ensure_second_lane(c); if (rc) return rc;
-            c->pipelined = true; c->next_lane = 0; c->have_previous = false;
+            c->pipelined = true; c->next_lane = 0; c->have_previous = false; c->last_probe_lane = -1;
         }
         const int lane = c->next_lane;
-        if (lane) { swap_path_buffers(c); std::swap(c->stream, c->alt_stream); }
-        c->accumulate_after = c->have_previous ? c->lane_done[lane ^ 1] : nullptr;
-        c->defer_resolve = true;
-        int rc = run_pass(c, false);
-        c->defer_resolve = false;
-        if (rc == RT_OK && hipEventRecord(c->lane_done[lane], c->stream) != hipSuccess) { set_error("rt_dispatch_rays: event record failed"); rc = RT_ERR_DEVICE; }
-        c->accumulate_after = nullptr;
-        if (lane) { swap_path_buffers(c); std::swap(c->stream, c->alt_stream); }
+        auto swap_lane = [&]() { if (lane) { swap_path_buffers(c); std::swap(c->stream, c->alt_stream); std::swap(c->d_sp_read, c->d_sp_read_alt); } };
+        swap_lane();
+        int rc = RT_OK;
+        auto hip_ok = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == RT_OK) { set_error("rt_dispatch_rays: %s failed: %s", what, hipGetErrorString(e)); rc = RT_ERR_DEVICE; } };
+        if (collect || (gather && c->sp_read_version[lane] != c->sp_version)) {
+            if (c->last_probe_lane >= 0 && c->last_probe_lane != lane) hip_ok(hipStreamWaitEvent(c->stream, c->probe_done[c->last_probe_lane], 0), "event wait");
+            if (rc == RT_OK && collect) { rc = run_pass(c, true); if (rc == RT_OK) c->sp_version++; } // raytracing.cpp:677-687
+            if (rc == RT_OK) hip_ok(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream), "sample point copy"); // :723-728
+            if (rc == RT_OK) { c->sp_read_version[lane] = c->sp_version; hip_ok(hipEventRecord(c->probe_done[lane], c->stream), "event record"); c->last_probe_lane = lane; }
+        }
+        if (rc == RT_OK) {
+            c->accumulate_after = c->have_previous ? c->lane_done[lane ^ 1] : nullptr;
+            c->defer_resolve = true;
+            rc = run_pass(c, false);                                                  // :734-741
+            c->defer_resolve = false; c->accumulate_after = nullptr;
+        }
+        if (rc == RT_OK) hip_ok(hipEventRecord(c->lane_done[lane], c->stream), "event record");
+        swap_lane();
         if (rc) return rc;
         c->next_lane ^= 1; c->have_previous = true;
         c->dispatch_index++;
@@ -896,6 +919,10 @@ int rt_dispatch_rays(rt_ctx* c) {
     }
     int rc = quiesce(c); if (rc) return rc;
     rc = ensure_path_buffers(c); if (rc) return rc;
+    if (c->n_points && c->sp_read_version[0] != c->sp_version) { // the last pipelined frame that collected samples ran on lane 1
+        RT_HIP(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream));
+        c->sp_read_version[0] = c->sp_version;
+    }
     auto refresh_hg = [&]() -> int { // node sums of the payloads the camera pass is about to read
         if (!(c->hg_enabled && c->hg_built)) return RT_OK;
         PassArgs a; fill_pass_args(c, a, false);
@@ -904,7 +931,10 @@ int rt_dispatch_rays(rt_ctx* c) {
     if (collect) { rc = run_pass(c, true); if (rc) return rc; }                       // raytracing.cpp:677-687
     if (c->flags & RT_FLAG_DOUBLE_DISPATCH) { rc = refresh_hg(); if (rc) return rc; }
     if (c->flags & RT_FLAG_DOUBLE_DISPATCH) { rc = run_pass(c, false); if (rc) return rc; } // :688-695
-    if (collect) RT_HIP(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream)); // :723-728
+    if (collect) {
+        RT_HIP(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream)); // :723-728
+        c->sp_read_version[0] = ++c->sp_version;
+    }
     rc = refresh_hg(); if (rc) return rc;
     rc = run_pass(c, false); if (rc) return rc;                                       // :734-741
     c->dispatch_index++;
@@ -951,7 +981,7 @@ int rt_read_sample_points(rt_ctx* c, uint32_t instance, RtSamplePoint* points, f
     if (!c || instance >= c->slices.size()) return RT_ERR_INVALID;
     { int qrc = quiesce(c); if (qrc) return qrc; }
     const TranslucentSlice& sl = c->slices[instance];
-    if (points) RT_HIP(hipMemcpyAsync(points, c->d_sp_read + sl.offset, sizeof(RtSamplePoint) * sl.count, hipMemcpyDeviceToHost, c->stream));
+    if (points) RT_HIP(hipMemcpyAsync(points, c->d_sp_write + sl.offset, /* == the read copy between dispatches; lane 0's may be one pipelined frame behind */ sizeof(RtSamplePoint) * sl.count, hipMemcpyDeviceToHost, c->stream));
     if (normals) RT_HIP(hipMemcpyAsync(normals, c->d_sp_normal + 3 * (size_t) sl.offset, 12 * (size_t) sl.count, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
     return RT_OK;

@@ -77,13 +77,17 @@ def test_c5_instanced_field_4k_every_ray(oracle_mod):
 
 
 def test_frames_in_flight_do_not_change_the_image(monkeypatch):
-    """Camera-only dispatches are pipelined over two streams with two sets of path buffers (RT_FRAMES_IN_FLIGHT,
-    default 2); only the accumulating shades wait for the frame before.  Same bits as one frame at a time, for one and
-    for several samples per pixel, with a tile split, and across a read in the middle of the sequence (which drains the
-    pipeline and starts it again)."""
-    from raytracer_amd import api, distributed
+    """Dispatches are pipelined over two streams with two sets of path buffers (RT_FRAMES_IN_FLIGHT, default 2); only a
+    frame's resolve kernel, and the sample-point pass with its copy, wait for the frame before.  Same bits as one frame
+    at a time: for one and for several samples per pixel, with a tile split, with the sample-point pass and both BSSRDF
+    gathers, across a read in the middle of the sequence (which drains the pipeline and starts it again) and across a
+    change of flags that stops the sample collection for two frames (odd number of collecting frames before it: the
+    newest sample points then sit in lane 1's copy)."""
+    from raytracer_amd import api, distributed, _abi
     cases = [(scenes.bunny(1280, 720, spp=1, bounces=2), None), (scenes.cornell(640, 360, spp=3, bounces=3), None),
-             (scenes.bunny(1920, 1080, spp=1, bounces=1), (1, 2))]
+             (scenes.bunny(1920, 1080, spp=1, bounces=1), (1, 2)),
+             (scenes.cornell(480, 270, spp=1, bounces=3, translucent_boxes=True), None),
+             (scenes.cornell_bunny(480, 270, spp=2, bounces=3), None)]
     results = {}
     for fif in ("1", "2"):
         monkeypatch.setenv("RT_FRAMES_IN_FLIGHT", fif)
@@ -93,14 +97,20 @@ def test_frames_in_flight_do_not_change_the_image(monkeypatch):
                 scene.setup(rt)
                 if split: rt.set_tile_split(*split)
                 mid = None
-                for f in range(9):
+                flags = _abi.RT_FLAG_COLLECT_SAMPLES | _abi.RT_FLAG_ENABLE_SSS
+                for f in range(10):
+                    if f == 7: rt.set_flags(flags & ~_abi.RT_FLAG_COLLECT_SAMPLES)
+                    if f == 9: rt.set_flags(flags)
                     distributed.render_frame(rt, scene.globals, f, 23)
-                    if f == 4: mid = rt.read_render_target()
-                results[(fif, k)] = (rt.read_accumulator(), rt.read_render_target(), mid)
+                    if f == 3: mid = rt.read_render_target()
+                pts = [rt.read_sample_points(i)[0] for i in range(rt.translucent_instance_count())]
+                results[(fif, k)] = (rt.read_accumulator(), rt.read_render_target(), mid, pts)
             finally:
                 rt.close()
     for k in range(len(cases)):
         a, b = results[("1", k)], results[("2", k)]
-        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
-        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), k
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), k
+        assert len(a[3]) == len(b[3]) and all(x.tobytes() == y.tobytes() for x, y in zip(a[3], b[3])), k
         assert a[0].any()
+    assert len(results[("2", 3)][3]) > 0 and len(results[("2", 4)][3]) > 0
