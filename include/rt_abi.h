@@ -12,8 +12,8 @@
  *
  * Every entry point returns an int status (RT_OK == 0) instead of the reference's abort() (prelude.h:185).
  * All work of a context takes effect in call order, as if on one HIP stream; calls are asynchronous unless stated
- * ("blocks").  On the context's own stream consecutive camera-only rt_dispatch_rays calls overlap on the GPU (two frames
- * in flight, accumulated in call order: same results); on a stream given with rt_set_stream everything runs on that stream.
+ * ("blocks").  On the context's own stream consecutive rt_dispatch_rays calls overlap on the GPU (two frames
+ * in flight; image and sample points are updated in call order: same results); on a stream given with rt_set_stream everything runs on that stream.
  * The context is not thread-safe (the reference keeps this state in namespace globals, raytracing.cpp:11-71).
  * Plain pointers and sizes only: no torch / HIP types appear in any signature.
  */
@@ -204,8 +204,8 @@ int  rt_set_gather_mode(rt_ctx* ctx, int hierarchical, float max_solid_angle);
 
 /* Raytracing::dispatch_rays (raytracing.cpp:652-747): [translucent_rgen] -> copy -> camera_rgen, then
  * accumulator_count += 1 and translucent_accumulator_count += collect (raytracing.cpp:744-745).  Asynchronous; up to
- * two dispatches are in flight at once when they touch nothing but the image (no sample collection, no BSSRDF gather,
- * no capture / count flags): every other call waits for both. */
+ * two dispatches are in flight at once (not with RT_FLAG_DOUBLE_DISPATCH / CAPTURE_HITS / COUNT_TRAVERSAL, the
+ * hierarchical gather, or a stream set by rt_set_stream): every other call waits for both. */
 int  rt_dispatch_rays(rt_ctx* ctx);
 
 /* ---- synchronisation and read-back -------------------------------------------------------------------- */
