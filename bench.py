@@ -78,6 +78,11 @@ def cpu_baseline(scene, budget_s, threads):
            {"n_node": c["nodes"] / rays, "n_tri": c["tris"] / rays, "n_inst": c["insts"] / rays}
 
 
+def out_frames_in_flight(args):
+    """frames the library overlaps on one GPU for this run (its default is 2; the hierarchical gather runs one at a time)"""
+    return 1 if args.hg is not None else max(1, min(2, int(os.environ.get("RT_FRAMES_IN_FLIGHT", "2"))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +196,32 @@ def main():
         crays = max(cs["rays_camera"] + cs["rays_probe"], 1)
         gpu_counts = {"n_node": cs["nodes_visited"] / crays, "n_tri": cs["tris_tested"] / crays, "n_inst": cs["instances_entered"] / crays}
 
+        # the same workload one frame at a time (a second context created with RT_FRAMES_IN_FLIGHT=1): the duration of
+        # a traversal launch that has the GPU to itself, next to the overlapped figure of the timed region above
+        alone = None
+        if world == 1 and out_frames_in_flight(args) > 1:
+            saved = os.environ.get("RT_FRAMES_IN_FLIGHT")
+            os.environ["RT_FRAMES_IN_FLIGHT"] = "1"
+            rt1 = api.Raytracer(local_rank)
+            if saved is None: del os.environ["RT_FRAMES_IN_FLIGHT"]
+            else: os.environ["RT_FRAMES_IN_FLIGHT"] = saved
+            try:
+                scene.setup(rt1)
+                n1 = max(8, min(args.steps, 48))
+                chain1 = distributed.FrameChain(scene.globals.frame_rng)
+                for k in range(2): distributed.render_frame(rt1, scene.globals, k, chain1)
+                rt1.set_flags(scene.flags | _abi.RT_FLAG_TIME_KERNELS | _abi.RT_FLAG_TIME_SAMPLED)
+                rt1.sync(); rt1.reset_stats()
+                t1 = time.perf_counter()
+                for k in range(n1): distributed.render_frame(rt1, scene.globals, 2 + k, chain1)
+                rt1.sync()
+                dt1 = time.perf_counter() - t1
+                s1 = rt1.get_stats()
+                alone = {"steps": n1, "Mrays_s": (s1["rays_camera"] + s1["rays_probe"]) / dt1 / 1e6, "ms_per_step": dt1 / n1 * 1e3,
+                         "mean_launch_ms": s1["traverse_ms"] / max(s1["traverse_launches_timed"], 1)}
+            finally:
+                rt1.close()
+
         cpu_line, model = None, None
         if not args.no_cpu and world == 1:  # the CPU baseline is reported at N = 1 only
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
@@ -230,7 +261,7 @@ def main():
                        "sample_points": points, "rays_per_step_per_gpu": rays / args.steps,
                        "parallelism": "sample-set split x%d + RCCL reduce" % world if world > 1 else "single GPU",
                        # consecutive steps overlap pairwise on the GPU (the library's default, RT_FRAMES_IN_FLIGHT)
-                       "frames_in_flight": 1 if args.hg is not None else max(1, min(2, int(os.environ.get("RT_FRAMES_IN_FLIGHT", "2"))))},
+                       "frames_in_flight": out_frames_in_flight(args)},
             "roofline": {"bound": "hbm", "kernel": "k_traverse", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_trav * rays_per_launch,
@@ -241,7 +272,11 @@ def main():
                          "mean_launch_ms": mean_launch_ms, "rays_per_launch": rays_per_launch,
                          "traverse_Mrays_s": rays_timed / (stats["traverse_ms"] * 1e-3) / 1e6 if stats["traverse_ms"] > 0 else None,
                          "launches_timed": stats["traverse_launches_timed"], "launches": stats["traverse_launches"],
-                         "model_counts": model, "gpu_bvh_counts": gpu_counts},
+                         "model_counts": model, "gpu_bvh_counts": gpu_counts,
+                         # launches of the timed region share the GPU with the other frame in flight; this is the same
+                         # kernel with the GPU to itself (frames one at a time), and what the job then runs at
+                         "one_frame_in_flight": None if alone is None else dict(alone, achieved=(b_trav * rays_per_launch) / (alone["mean_launch_ms"] * 1e-3) / 1e9,
+                                                                                frac=(b_trav * rays_per_launch) / (alone["mean_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS)},
             "cpu_baseline": cpu_line,
         }
         # acceleration-structure builds are outside the timed loop: reported separately
