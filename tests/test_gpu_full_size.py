@@ -114,3 +114,34 @@ def test_frames_in_flight_do_not_change_the_image(monkeypatch):
         assert len(a[3]) == len(b[3]) and all(x.tobytes() == y.tobytes() for x, y in zip(a[3], b[3])), k
         assert a[0].any()
     assert len(results[("2", 3)][3]) > 0 and len(results[("2", 4)][3]) > 0
+
+
+def test_top_level_rebuilds_between_pipelined_frames(monkeypatch):
+    """The reference rebuilds the top level every frame (raytracing.cpp:652-676).  A rebuild, like every entry point other
+    than a dispatch, first drains both lanes of the frame pipeline: frames rendered with a moving instance, with and
+    without frames in flight, give the same bits, and so do statistics calls dropped into a run of dispatches."""
+    from raytracer_amd import api, distributed
+    scene = scenes.bunny(960, 540, spp=1, bounces=2)
+    images = []
+    for fif in ("1", "2"):
+        monkeypatch.setenv("RT_FRAMES_IN_FLIGHT", fif)
+        rt = api.Raytracer(0)
+        try:
+            rt.update_resolution(scene.width, scene.height)
+            handles = [rt.build_blas(geos) for geos in scene.blas]
+            rt.set_flags(scene.flags); rt.set_globals(scene.globals)
+            for f in range(8):
+                if f < 4 or f == 6:   # frames 4, 5 and 7 reuse the top level of the frame before: those overlap
+                    inst = []
+                    for m, b in scene.instances:
+                        m = np.array(m, dtype=np.float32, copy=True)
+                        if b == 0: m[3, 0] += 0.01 * f   # row vectors: translation in row 3
+                        inst.append((m, handles[b]))
+                    rt.build_tlas(inst)
+                distributed.render_frame(rt, scene.globals, f, 31)
+                if f == 5: assert rt.get_stats()["rays_camera"] > 0
+            images.append((rt.read_accumulator(), rt.read_render_target()))
+        finally:
+            rt.close()
+    assert np.array_equal(images[0][0].view(np.uint32), images[1][0].view(np.uint32))
+    assert np.array_equal(images[0][1], images[1][1]) and images[0][0].any()
