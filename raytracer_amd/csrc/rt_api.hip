@@ -103,6 +103,9 @@ struct rt_ctx {
     uint64_t sp_version = 0, sp_read_version[2] = { 0, 0 };
     hipEvent_t accumulate_after = nullptr; // run_pass: the frame's resolve waits for this (the previous frame's end)
     bool defer_resolve = false;            // run_pass: pipelined frame (k_frame_resolve instead of the resolve inside k_shade)
+    // pipelined frames do not write the 8-bit render target; rt_read_render_target derives it from the accumulator
+    // (k_resolve_only: the same expression on the same sums) when the last frames left it behind
+    bool render_target_stale = false; u32 render_target_frames = 0;
     // BSSRDF tables
     float* d_table[2] = { nullptr, nullptr }; int table_texels[2] = { 0, 0 }; int profile = 0;
     // stats
@@ -344,6 +347,7 @@ int run_pass(rt_ctx* c, bool probe) {
     // emission after a path's last shade, no resolve kernel either (finished paths resolve their pixel in k_shade)
     bool fused = !probe && !gather;
     a.defer_resolve = (c->defer_resolve && fused) ? 1u : 0u;
+    a.lazy_render_target = c->defer_resolve ? 1u : 0u;
     for (u32 s = 0; s < c->g.samples_per_pixel; s++) {
         int rc = RT_OK;
         if (probe) { rc = launch_probe_raygen(c->stream, a, s); if (rc) return rc; }
@@ -464,6 +468,7 @@ int rt_update_resolution(rt_ctx* c, uint32_t w, uint32_t h) {
     RT_HIP(hipMalloc(&c->d_render_target, (size_t) w * h * 4));
     RT_HIP(hipMemsetAsync(c->d_accumulator, 0, (size_t) w * h * 16, c->stream));
     RT_HIP(hipMemsetAsync(c->d_render_target, 0, (size_t) w * h * 4, c->stream));
+    c->render_target_stale = false;
     return ensure_path_buffers(c);
 }
 
@@ -915,6 +920,7 @@ int rt_dispatch_rays(rt_ctx* c) {
         c->dispatch_index++;
         c->g.accumulator_count += 1;                                                  // :744
         c->g.translucent_accumulator_count += (c->flags & RT_FLAG_COLLECT_SAMPLES) ? 1u : 0u; // :745
+        c->render_target_stale = true; c->render_target_frames = c->g.accumulator_count;
         return RT_OK;
     }
     int rc = quiesce(c); if (rc) return rc;
@@ -937,6 +943,7 @@ int rt_dispatch_rays(rt_ctx* c) {
     }
     rc = refresh_hg(); if (rc) return rc;
     rc = run_pass(c, false); if (rc) return rc;                                       // :734-741
+    c->render_target_stale = false;
     c->dispatch_index++;
     c->g.accumulator_count += 1;                                                      // :744
     c->g.translucent_accumulator_count += (c->flags & RT_FLAG_COLLECT_SAMPLES) ? 1u : 0u; // :745
@@ -960,6 +967,12 @@ int rt_read_accumulator(rt_ctx* c, float* rgba) {
 int rt_read_render_target(rt_ctx* c, uint8_t* rgba8) {
     if (!c || !rgba8 || !c->d_render_target) return RT_ERR_INVALID;
     { int qrc = quiesce(c); if (qrc) return qrc; }
+    if (c->render_target_stale) {
+        PassArgs a; fill_pass_args(c, a, false);
+        a.g.accumulator_count = c->render_target_frames;
+        int rc = launch_resolve_only(c->stream, a); if (rc) return rc;
+        c->render_target_stale = false;
+    }
     RT_HIP(hipMemcpyAsync(rgba8, c->d_render_target, (size_t) c->width * c->height * 4, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -1027,6 +1040,7 @@ int rt_resolve_render_target(rt_ctx* c) {
     if (!c || !c->d_accumulator) return RT_ERR_INVALID;
     { int qrc = quiesce(c); if (qrc) return qrc; }
     PassArgs a; fill_pass_args(c, a, false);
+    c->render_target_stale = false;
     return launch_resolve_only(c->stream, a);
 }
 

@@ -124,13 +124,14 @@ RT_DEV void resolve_pixel(const PassArgs& a, u32 pixel, float* tot /* [4] */) {
     if (a.g.accumulator_count != 0) prev = ((const float4*) a.accumulator)[pixel];
     float pv[4] = { prev.x, prev.y, prev.z, prev.w };
     float denom = (float) (a.g.accumulator_count + 1u);
-    unsigned char rt[4];
     for (int k = 0; k < 4; k++) {
-        tot[k] = tot[k] / spp;                                   // raytracing.hlsl:153
+        if (spp != 1.0f) tot[k] = tot[k] / spp;                  // raytracing.hlsl:153 (x / 1 is x: the division is skipped, uniformly)
         if (a.g.accumulator_count != 0) tot[k] = tot[k] + pv[k]; // :155-158
-        rt[k] = to_unorm8(sqrtf(tot[k] / denom));                // :161
     }
     ((float4*) a.accumulator)[pixel] = make_float4(tot[0], tot[1], tot[2], tot[3]);
+    if (a.lazy_render_target) return; // pipelined frames: the 8-bit image is derived when it is read (k_resolve_only: four divisions and square roots per pixel that most frames of a sequence never show)
+    unsigned char rt[4];
+    for (int k = 0; k < 4; k++) rt[k] = to_unorm8(sqrtf(tot[k] / denom)); // :161
     ((uchar4*) a.render_target)[pixel] = make_uchar4(rt[0], rt[1], rt[2], rt[3]);
 }
 
