@@ -557,7 +557,7 @@ int rt_build_blas(rt_ctx* c, const RtGeometry* geometries, int n, rt_blas* out) 
     RT_HIP(hipMalloc(&b.d_geoms, b.geoms.size() * sizeof(GeomRec)));
     RT_HIP(hipMalloc(&b.d_tri_geometry, tri_geometry.size() * 4));
     // nodes and triangles share one allocation: an instance record addresses both with one pointer + a 32-bit offset
-    RT_HIP(hipMalloc(&b.d_nodes, n_nodes * sizeof(PackedNode) + b.n_tris * sizeof(TriRec)));
+    RT_HIP(hipMalloc(&b.d_nodes, n_nodes * sizeof(PackedNode) + 3 * (size_t) b.n_tris * sizeof(TriRec))); // three copies of the triangles (TriRec)
     b.d_tris = (TriRec*) (b.d_nodes + n_nodes);
     RT_HIP(hipMalloc(&b.d_perm, b.n_tris * 4));
     RT_HIP(hipMemcpyAsync(b.d_verts, b.verts.data(), b.verts.size() * sizeof(RtVertex), hipMemcpyHostToDevice, c->stream));
@@ -612,9 +612,9 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
             c->g.translucent_instance_stride = std::max(c->g.translucent_instance_stride, counts[instances[i].blas]);
         }
         invert_affine(instances[i].transform, rec[i].world_to_object);
-        rec[i].nodes = b.d_nodes; rec[i].tris_offset = (u32) ((const char*) b.d_tris - (const char*) b.d_nodes); rec[i].bound = b.info.bound;
+        rec[i].nodes = b.d_nodes; rec[i].tris_offset = (u32) ((const char*) b.d_tris - (const char*) b.d_nodes); rec[i].bound = b.info.bound; rec[i].tris_copy_bytes = (u32) (b.n_tris * sizeof(TriRec));
         for (int k = 0; k < 3; k++) { rec[i].ctr[k] = b.info.ctr[k]; rec[i].inv_h[k] = b.info.inv_h[k]; }
-        rec[i].pad[0] = rec[i].pad[1] = 0.0f;
+        rec[i].pad = 0.0f;
         memcpy(shade[i].object_to_world, instances[i].transform, 64);
         shade[i].vertices = b.d_verts; shade[i].indices = b.d_indices; shade[i].geoms = b.d_geoms; shade[i].tris = b.d_tris;
         shade[i].instance_id = instance_id; shade[i].vertex_count = (u32) b.verts.size();

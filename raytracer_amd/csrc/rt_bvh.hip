@@ -208,18 +208,19 @@ __global__ void k_emit_single(const Aabb* __restrict__ scene, const u32* __restr
 
 __global__ void k_trirecs(const u32* __restrict__ perm, const RtVertex* __restrict__ verts, const uint16_t* __restrict__ indices,
                           const u32* __restrict__ tri_geometry, const GeomRec* __restrict__ geoms, u32 n, TriRec* __restrict__ out) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 3u * n) return;
+    const u32 copy = j / n, i = j - copy * n; // copy c: coordinates in the order (c + 1, c + 2, c) mod 3 (TriRec)
     u32 prim = perm[i];
     TriRec t;
     const float* p0 = verts[indices[3 * prim + 0]].position;
     const float* p1 = verts[indices[3 * prim + 1]].position;
     const float* p2 = verts[indices[3 * prim + 2]].position;
-    for (int k = 0; k < 3; k++) { t.v0[k] = p0[k]; t.v1[k] = p1[k]; t.v2[k] = p2[k]; }
+    for (int k = 0; k < 3; k++) { const int s = (int) ((copy + 1u + (u32) k) % 3u); t.v0[k] = p0[s]; t.v1[k] = p1[s]; t.v2[k] = p2[s]; }
     t.prim_global = prim;
     t.geometry = tri_geometry[prim];
     t.prim_local = prim - geoms[t.geometry].first_tri;
-    out[i] = t;
+    out[j] = t;
 }
 
 int lbvh_workspace_reserve(LbvhWorkspace& w, u32 n) {
@@ -380,7 +381,7 @@ static int lbvh_build_impl(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, S
 int lbvh_write_trirecs(hipStream_t s, const u32* perm, const RtVertex* verts, const uint16_t* indices,
                        const u32* tri_geometry, const GeomRec* geoms, u32 n_tris, TriRec* out) {
     if (n_tris == 0) return RT_OK;
-    hipLaunchKernelGGL(k_trirecs, grid_for(n_tris), dim3(BT), 0, s, perm, verts, indices, tri_geometry, geoms, n_tris, out);
+    hipLaunchKernelGGL(k_trirecs, grid_for(3 * (size_t) n_tris), dim3(BT), 0, s, perm, verts, indices, tri_geometry, geoms, n_tris, out);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

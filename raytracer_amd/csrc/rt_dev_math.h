@@ -139,17 +139,24 @@ RT_DEV f3 xform_point44(const float* m, f3 p) {        // mul(float4(p, 1), M).x
 }
 
 // ---- S4: watertight ray/triangle test, back faces culled -----------------------------------------------------
+// S3 (Woop et al.): kz = the axis of the largest |d| (the first one on ties), kx = kz + 1, ky = kz + 2 (mod 3), kx and
+// ky exchanged when d[kz] < 0 (keeps the winding); the ray is sheared and scaled so that it runs along +z.
+// The triangles are stored three times, with their coordinates in the orders (1, 2, 0), (2, 0, 1) and (0, 1, 2)
+// (TriRec, rt_dev_scene.h), and a ray reads the copy of its kz: the per-vertex permutation (18 selects per triangle)
+// is done once per ray, on its origin.  The exchange of kx and ky is not applied to the coordinates either: with the
+// x and y roles exchanged an edge function Cx By - Cy Bx becomes Cy Bx - Cx By = (-Cx) By - Cy (-Bx) -- each product
+// has one x and one y factor, a - b is a + (-b) and the sum commutes -- so the test runs in the unexchanged order with
+// the three sheared x coordinates negated (`flip`): every operation of the contract gets the same operands (up to
+// their order in commutative operations), hence the same t, u, v, bit for bit, signs of zeros included.
 struct RayPrep {
-    f3 o;
-    int kx, ky, kz;
-    float sx, sy, sz;
+    f3 o;              // origin in the order (kz + 1, kz + 2, kz)
+    int kz;
+    u32 flip;          // 0x80000000 when d[kz] < 0
+    float sx, sy, sz;  // d[kz + 1] / d[kz], d[kz + 2] / d[kz], 1 / d[kz]
 };
 
 RT_DEV RayPrep prepare_ray(f3 o, f3 d) {
     RayPrep r;
-    r.o = o;
-    // kz = the axis of the largest |d| (the first one on ties), kx = kz + 1, ky = kz + 2 (mod 3), kx and ky exchanged
-    // when d[kz] < 0 (keeps the winding); written as selects on two comparisons
     const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
     const bool y_over_x = ay > ax;
     const bool z_over = az > (y_over_x ? ay : ax);
@@ -157,23 +164,25 @@ RT_DEV RayPrep prepare_ray(f3 o, f3 d) {
     const float dz = z_over ? d.z : (y_over_x ? d.y : d.x);
     const float d1 = z_over ? d.x : (y_over_x ? d.z : d.y); // d[kz + 1]
     const float d2 = z_over ? d.y : (y_over_x ? d.x : d.z); // d[kz + 2]
-    const int k1 = z_over ? 0 : (y_over_x ? 2 : 1), k2 = z_over ? 1 : (y_over_x ? 0 : 2);
-    const bool flip = dz < 0.0f;
-    r.kx = flip ? k2 : k1; r.ky = flip ? k1 : k2; r.kz = kz;
-    r.sx = (flip ? d2 : d1) / dz;
-    r.sy = (flip ? d1 : d2) / dz;
+    r.o = mk3(z_over ? o.x : (y_over_x ? o.z : o.y), z_over ? o.y : (y_over_x ? o.x : o.z), z_over ? o.z : (y_over_x ? o.y : o.x));
+    r.kz = kz;
+    r.flip = dz < 0.0f ? 0x80000000u : 0u;
+    r.sx = d1 / dz;
+    r.sy = d2 / dz;
     r.sz = 1.0f / dz;
     return r;
 }
 
 // The barycentrics of a candidate are returned as the numerators V, W and the denominator det: only the closest hit
 // of a ray needs u = V / det and v = W / det, so the caller divides once per ray (same operands, same quotient).
+// p0, p1, p2: the vertices from the triangle copy of the ray's kz (coordinates in the order of r.o)
 RT_DEV bool intersect_triangle(const RayPrep& r, f3 p0, f3 p1, f3 p2, float& t_out, float& v_num, float& w_num, float& det_out) {
     f3 A = p0 - r.o, B = p1 - r.o, C = p2 - r.o;
-    float Akz = comp3(A, r.kz), Bkz = comp3(B, r.kz), Ckz = comp3(C, r.kz);
-    float Ax = comp3(A, r.kx) - r.sx * Akz, Ay = comp3(A, r.ky) - r.sy * Akz;
-    float Bx = comp3(B, r.kx) - r.sx * Bkz, By = comp3(B, r.ky) - r.sy * Bkz;
-    float Cx = comp3(C, r.kx) - r.sx * Ckz, Cy = comp3(C, r.ky) - r.sy * Ckz;
+    float Akz = A.z, Bkz = B.z, Ckz = C.z;
+    float Ax = A.x - r.sx * Akz, Ay = A.y - r.sy * Akz;
+    float Bx = B.x - r.sx * Bkz, By = B.y - r.sy * Bkz;
+    float Cx = C.x - r.sx * Ckz, Cy = C.y - r.sy * Ckz;
+    Ax = as_f32(as_u32(Ax) ^ r.flip); Bx = as_f32(as_u32(Bx) ^ r.flip); Cx = as_f32(as_u32(Cx) ^ r.flip); // kx and ky exchanged (see RayPrep)
     float U = Cx * By - Cy * Bx;
     float V = Ax * Cy - Ay * Cx;
     float W = Bx * Ay - By * Ax;

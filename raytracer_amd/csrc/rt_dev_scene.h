@@ -43,7 +43,9 @@ typedef _Float16 rt_half2 __attribute__((ext_vector_type(2)));
 RT_DEV float half_lo(u32 w) { return (float) __builtin_bit_cast(rt_half2, w).x; }
 RT_DEV float half_hi(u32 w) { return (float) __builtin_bit_cast(rt_half2, w).y; }
 
-// 48 B: triangle in leaf order, fetched as 3 x 16 B
+// 48 B: triangle in leaf order, fetched as 3 x 16 B.  A BLAS holds its n triangles three times, records [c n, (c + 1) n)
+// with the coordinates of every vertex in the order (c + 1, c + 2, c) mod 3: a ray whose dominant direction axis is kz
+// reads copy kz and needs no permutation (RayPrep, rt_dev_math.h).  Everything else is the same in the three copies.
 struct alignas(16) TriRec {
     float v0[3], v1[3], v2[3];
     u32 prim_global; // primitive index in the concatenated index buffer of the BLAS (geometry order)
@@ -58,7 +60,8 @@ struct alignas(16) InstRec {
     u32   tris_offset;         // byte offset of the BLAS's TriRec array from `nodes` (one allocation per BLAS)
     float bound;               // TreeInfo.bound of the BLAS, here so that entering an instance costs no dependent load
     float ctr[3], inv_h[3];    // frame of the BLAS's packed nodes
-    float pad[2];
+    u32   tris_copy_bytes;     // size of one copy of the TriRec array (copy kz starts at tris_offset + kz * tris_copy_bytes)
+    float pad;
 };
 
 struct SceneView {
@@ -175,7 +178,8 @@ RT_DEV void trace_bottom_level(const SceneView& sc, f3 o, f3 d, TraceState& S) {
     f3 od = xform_dir43(w2o, d);
     S.rp = prepare_ray(oo, od);
     unsigned long long pn = ((unsigned long long) as_u32(m3.y) << 32) | as_u32(m3.x);
-    S.nodes = (const RT_GLOBAL PackedNode*) pn; S.tris = (const RT_GLOBAL TriRec*) (pn + as_u32(m3.z));
+    S.nodes = (const RT_GLOBAL PackedNode*) pn;
+    S.tris = (const RT_GLOBAL TriRec*) (pn + as_u32(m3.z) + (unsigned long long) ((u32) S.rp.kz * as_u32(m5.z))); // the triangle copy of this ray's kz
     S.br = make_box_ray(oo, od, m3.w, mk3(m4.x, m4.y, m4.z), mk3(m4.w, m5.x, m5.y));
     S.bottom = true;
 }
@@ -196,7 +200,7 @@ RT_DEV void trace_resume_top_level(const SceneView& sc, const Stack& st, TraceSt
 RT_DEV void trace_begin(const SceneView& sc, f3 o, f3 d, float tmax, TraceState& S) {
     S.best.t = tmax; S.best.u = 0.0f; S.best.v = 0.0f; S.best.inst = -1; S.best.tri = -1; S.best.prim_global = 0;
     S.have_hit = false; S.cur_inst = -1; S.tris = nullptr; S.det = 1.0f;
-    S.rp.o = o; S.rp.kx = 0; S.rp.ky = 1; S.rp.kz = 2; S.rp.sx = S.rp.sy = S.rp.sz = 0.0f;
+    S.rp.o = o; S.rp.kz = 2; S.rp.flip = 0u; S.rp.sx = S.rp.sy = S.rp.sz = 0.0f;
     trace_top_level(sc, o, d, S);
     // a NaN in the ray makes every triangle test fail (S4 compares with NaN are false): the answer is a miss, and
     // it must not cost a walk through the whole tree (NaN box tests pass conservatively).  Such rays do occur:
