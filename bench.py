@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--instances", type=int, default=52743)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-alone", action="store_true",
+                    help="skip the one-frame-at-a-time leg (roofline.one_frame_in_flight), e.g. under rocprofv3, so that the "
+                         "kernel statistics hold only launches of the timed regime")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a one-GPU box: every rank uses GPU 0 and the collectives go through gloo (checks the "
                          "multi-rank code path; the numbers mean nothing)")
@@ -199,7 +202,7 @@ def main():
         # the same workload one frame at a time (a second context created with RT_FRAMES_IN_FLIGHT=1): the duration of
         # a traversal launch that has the GPU to itself, next to the overlapped figure of the timed region above
         alone = None
-        if world == 1 and out_frames_in_flight(args) > 1:
+        if world == 1 and out_frames_in_flight(args) > 1 and not args.no_alone:
             saved = os.environ.get("RT_FRAMES_IN_FLIGHT")
             os.environ["RT_FRAMES_IN_FLIGHT"] = "1"
             rt1 = api.Raytracer(local_rank)

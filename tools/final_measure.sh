@@ -6,9 +6,9 @@ tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 timeout -k 10 300 python3 bench.py > gpurun_out/${tag}_c2.json 2> gpurun_out/${tag}_c2.err || { echo "c2 failed"; tail -5 gpurun_out/${tag}_c2.err; exit 1; }
 echo "c2 done"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof_c2 -o c2 --output-format csv -- python3 bench.py --no-cpu > gpurun_out/${tag}_prof_c2.log 2>&1 || { echo "rocprof c2 failed"; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof_c2 -o c2 --output-format csv -- python3 bench.py --no-cpu --no-alone > gpurun_out/${tag}_prof_c2.log 2>&1 || { echo "rocprof c2 failed"; exit 1; }
 echo "rocprof c2 done"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof_c3 -o c3 --output-format csv -- python3 bench.py --no-cpu --workload c3 --spp 4 > gpurun_out/${tag}_prof_c3.log 2>&1 || { echo "rocprof c3 failed"; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof_c3 -o c3 --output-format csv -- python3 bench.py --no-cpu --no-alone --workload c3 --spp 4 > gpurun_out/${tag}_prof_c3.log 2>&1 || { echo "rocprof c3 failed"; exit 1; }
 echo "rocprof c3 done"
 for w in c3 c3t c4; do
   timeout -k 10 300 python3 bench.py --no-cpu --workload $w > gpurun_out/${tag}_$w.json 2> gpurun_out/${tag}_$w.err || { echo "$w failed"; tail -5 gpurun_out/${tag}_$w.err; exit 1; }

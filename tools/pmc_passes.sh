@@ -15,6 +15,6 @@ groups=(
 n=0
 for g in "${groups[@]}"; do
   n=$((n+1))
-  timeout -s KILL 150 rocprofv3 --pmc $g -d gpurun_out/pmc_${tag}_$n -o p --output-format csv -- python3 bench.py --no-cpu "$@" > gpurun_out/pmc_${tag}_$n.log 2>&1 || { echo "pass $n failed"; tail -5 gpurun_out/pmc_${tag}_$n.log; exit 1; }
+  timeout -s KILL 150 rocprofv3 --pmc $g -d gpurun_out/pmc_${tag}_$n -o p --output-format csv -- python3 bench.py --no-cpu --no-alone "$@" > gpurun_out/pmc_${tag}_$n.log 2>&1 || { echo "pass $n failed"; tail -5 gpurun_out/pmc_${tag}_$n.log; exit 1; }
   echo "pass $n ok"
 done
