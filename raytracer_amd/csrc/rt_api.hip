@@ -159,7 +159,7 @@ int alloc_path_buffers(rt_ctx* c, u32 segs) {
     c->ps.thr_x = take(); c->ps.thr_y = take(); c->ps.thr_z = take();
     c->ps.rad_x = take(); c->ps.rad_y = take(); c->ps.rad_z = take(); c->ps.alpha = take();
     c->ps.fd_x = take(); c->ps.fd_y = take(); c->ps.fd_z = take();
-    c->ps.sum_x = take(); c->ps.sum_y = take(); c->ps.sum_z = take(); c->ps.sum_a = take();
+    c->ps.sum_x = take(); c->ps.sum_y = take(); c->ps.sum_z = take(); c->ps.sum_a = take(); // consecutive: k_shade / k_frame_resolve also use them as one float4 array
     for (int k = 0; k < 2; k++) {
         c->st[k].rng = (u32*) take(); c->st[k].thr_x = take(); c->st[k].thr_y = take(); c->st[k].thr_z = take();
         c->st[k].rad_x = take(); c->st[k].rad_y = take(); c->st[k].rad_z = take();

@@ -157,7 +157,11 @@ __global__ __launch_bounds__(BT) void k_frame_resolve(PassArgs a) {
     u32 px, py;
     if (!thread_pixel(a, t, px, py)) return;
     u32 pixel = py * a.width + px;
-    float tot[4] = { a.ps.sum_x[pixel], a.ps.sum_y[pixel], a.ps.sum_z[pixel], a.ps.sum_a[pixel] };
+    float tot[4];
+    if (a.g.samples_per_pixel == 1u) { // one 16-byte record per pixel (see k_shade)
+        const float4 v = ((const float4*) a.ps.sum_x)[pixel];
+        tot[0] = v.x; tot[1] = v.y; tot[2] = v.z; tot[3] = v.w;
+    } else { tot[0] = a.ps.sum_x[pixel]; tot[1] = a.ps.sum_y[pixel]; tot[2] = a.ps.sum_z[pixel]; tot[3] = a.ps.sum_a[pixel]; }
     resolve_pixel(a, pixel, tot);
 }
 
@@ -422,7 +426,12 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             if (sample_index + 1u < a.g.samples_per_pixel) {
                 a.ps.rng[path] = rng; // the next sample of this pixel continues the stream (raytracing.hlsl:130,141)
                 for (int k = 0; k < 4; k++) sum[k][path] = tot[k];
-            } else if (a.defer_resolve) { for (int k = 0; k < 4; k++) sum[k][path] = tot[k]; } // k_frame_resolve adds it in
+            } else if (a.defer_resolve) { // k_frame_resolve adds it in
+                // with one sample per pixel nothing reads the four sum arrays as such: they are consecutive in the arena
+                // (rt_api.hip) and hold one float4 per pixel instead -- one 16-byte store, 128-byte runs per 8 pixels
+                if (a.g.samples_per_pixel == 1u) ((float4*) a.ps.sum_x)[path] = make_float4(tot[0], tot[1], tot[2], tot[3]);
+                else for (int k = 0; k < 4; k++) sum[k][path] = tot[k];
+            }
             else resolve_pixel(a, path, tot);
         }
         if (alive) { no = o + r.t * d; nd = r.scatter; }       // :118-119
