@@ -71,8 +71,10 @@ RT_DEV f3 world_space_normal(const InstShade& in, u32 prim_global, float bu, flo
 }
 
 // payload_t_in: the bounce index (or +inf when translucent emission is ignored), raytracing.hlsl:102-107
+// emission_only: the caller uses nothing but r.emission (the path ends here whatever the surface does and its RNG state
+// is dead): a Lambert hit, whose emission is zero, then skips the normal (three vertex fetches) and the scatter draw
 RT_DEV void shade_ray(const ShadeScene& sc, const RtGlobals& g, float fudge, f3 o, f3 d, const HitOut& h,
-                      float payload_t_in, u32& rng, ShadeOut& r) {
+                      float payload_t_in, u32& rng, ShadeOut& r, bool emission_only = false) {
     r.gather = false; r.ti = -1; r.transmitted_fresnel = 0.0f; r.hit_point = mk3(0.0f, 0.0f, 0.0f);
     r.geometry = -1; r.primitive = -1;
     if (h.inst < 0) { // miss, raytracing.hlsl:201-207
@@ -83,9 +85,13 @@ RT_DEV void shade_ray(const ShadeScene& sc, const RtGlobals& g, float fudge, f3 
     const TriRec& tr = in.tris[h.tri];
     const GeomRec& geo = in.geoms[tr.geometry];
     r.geometry = (int) tr.geometry; r.primitive = (int) tr.prim_local;
-    f3 normal = world_space_normal(in, tr.prim_global, h.u, h.v, d);
     f3 color = mk3(geo.color[0], geo.color[1], geo.color[2]);
     r.t = h.t;
+    if (geo.shader == RT_SHADER_LAMBERT && emission_only) {
+        r.scatter = mk3(0.0f, 0.0f, 0.0f); r.reflectance = r.scatter; r.emission = r.scatter;
+        return;
+    }
+    f3 normal = world_space_normal(in, tr.prim_global, h.u, h.v, d);
     if (geo.shader == RT_SHADER_LAMBERT) { // raytracing.hlsl:170-179
         r.scatter = random_on_hemisphere(rng, normal);
         r.reflectance = color * dot3(normal, r.scatter);

@@ -366,6 +366,9 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
     f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
     ShadeOut r;
     f3 thr_prev = mk3(1.0f, 1.0f, 1.0f), rad = mk3(0.0f, 0.0f, 0.0f), thr = mk3(0.0f, 0.0f, 0.0f);
+    // the last bounce of a dispatch's last sample in the fused pass: every path ends here and only the emission of what
+    // it hit still counts -- the ray origin, the RNG state and (shade_ray) the scattering of Lambert surfaces are not needed
+    const bool tail = FUSED && !PRIMARY && !a.capture && bounce == a.g.bounces_per_sample && sample_index + 1u == a.g.samples_per_pixel;
     if (PRIMARY) {
         u32 px = 0, py = 0;
         active = thread_pixel(a, qi, px, py);
@@ -386,11 +389,11 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         if (active) {
             const RayQueue& q = a.q[inq];
             path = q.path[qi];
-            o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
+            if (!tail) o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
             d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
             if (FUSED) { // the state travels with the ray
                 const SlotState& st = a.st[inq];
-                rng = st.rng[qi];
+                if (!tail) rng = st.rng[qi];
                 thr_prev = mk3(st.thr_x[qi], st.thr_y[qi], st.thr_z[qi]);
                 rad = mk3(st.rad_x[qi], st.rad_y[qi], st.rad_z[qi]);
             } else {
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         h.t = a.hits.t[qi]; h.u = a.hits.u[qi]; h.v = a.hits.v[qi]; h.inst = a.hits.inst[qi]; h.tri = a.hits.tri[qi];
         h.prim_global = 0;
         float payload_t = a.probe ? inf_f32() : (float) bounce; // raytracing.hlsl:102-107
-        shade_ray(a.shade, a.g, a.fudge, o, d, h, payload_t, rng, r);
+        shade_ray(a.shade, a.g, a.fudge, o, d, h, payload_t, rng, r, tail);
         rad = rad + r.emission * thr_prev;            // :113
         thr = thr_prev * r.reflectance;               // :114
         bool alive = any3(r.reflectance);             // :116
@@ -449,6 +452,10 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         }
     }
     u32 total;
+    if (tail) { // no path goes on: nothing to compact
+        if (threadIdx.x == 0) a.seg_count[inq ^ 1u][blockIdx.x] = 0u;
+        return;
+    }
     if (FUSED) {
         // Survivors are compacted to the front of the segment, grouped by the octant of their new direction when
         // a.ray_sort is set: rays of one origin neighbourhood (the tile) and one octant walk the BVH alike, which cuts
