@@ -71,8 +71,9 @@ RT_DEV f3 world_space_normal(const InstShade& in, u32 prim_global, float bu, flo
 }
 
 // payload_t_in: the bounce index (or +inf when translucent emission is ignored), raytracing.hlsl:102-107
-// emission_only: the caller uses nothing but r.emission (the path ends here whatever the surface does and its RNG state
-// is dead): a Lambert hit, whose emission is zero, then skips the normal (three vertex fetches) and the scatter draw
+// emission_only: the caller uses nothing but r.emission and the RNG state (the path ends here whatever the surface
+// does): a Lambert hit, whose emission is zero, then skips the normal (three vertex fetches) and the scatter direction,
+// and only advances the RNG by the two draws of random_on_sphere
 RT_DEV void shade_ray(const ShadeScene& sc, const RtGlobals& g, float fudge, f3 o, f3 d, const HitOut& h,
                       float payload_t_in, u32& rng, ShadeOut& r, bool emission_only = false) {
     r.gather = false; r.ti = -1; r.transmitted_fresnel = 0.0f; r.hit_point = mk3(0.0f, 0.0f, 0.0f);
@@ -89,6 +90,7 @@ RT_DEV void shade_ray(const ShadeScene& sc, const RtGlobals& g, float fudge, f3 
     r.t = h.t;
     if (geo.shader == RT_SHADER_LAMBERT && emission_only) {
         r.scatter = mk3(0.0f, 0.0f, 0.0f); r.reflectance = r.scatter; r.emission = r.scatter;
+        (void) random01(rng); (void) random11(rng); // random.hlsl:70-75: the stream goes on into the pixel's next sample
         return;
     }
     f3 normal = world_space_normal(in, tr.prim_global, h.u, h.v, d);

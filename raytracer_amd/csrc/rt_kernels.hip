@@ -366,9 +366,11 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
     f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
     ShadeOut r;
     f3 thr_prev = mk3(1.0f, 1.0f, 1.0f), rad = mk3(0.0f, 0.0f, 0.0f), thr = mk3(0.0f, 0.0f, 0.0f);
-    // the last bounce of a dispatch's last sample in the fused pass: every path ends here and only the emission of what
-    // it hit still counts -- the ray origin, the RNG state and (shade_ray) the scattering of Lambert surfaces are not needed
-    const bool tail = FUSED && !PRIMARY && !a.capture && bounce == a.g.bounces_per_sample && sample_index + 1u == a.g.samples_per_pixel;
+    // the last bounce in the fused pass: every path ends here and only the emission of what it hit still counts -- the
+    // ray origin and (shade_ray) the scattering of Lambert surfaces are not needed, nor the RNG state unless the pixel
+    // has another sample to come in this dispatch
+    const bool tail = FUSED && !PRIMARY && !a.capture && bounce == a.g.bounces_per_sample;
+    const bool rng_dead = tail && sample_index + 1u == a.g.samples_per_pixel;
     if (PRIMARY) {
         u32 px = 0, py = 0;
         active = thread_pixel(a, qi, px, py);
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
             if (FUSED) { // the state travels with the ray
                 const SlotState& st = a.st[inq];
-                if (!tail) rng = st.rng[qi];
+                if (!rng_dead) rng = st.rng[qi];
                 thr_prev = mk3(st.thr_x[qi], st.thr_y[qi], st.thr_z[qi]);
                 rad = mk3(st.rad_x[qi], st.rad_y[qi], st.rad_z[qi]);
             } else {
