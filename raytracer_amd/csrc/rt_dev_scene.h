@@ -117,8 +117,10 @@ struct BoxRay {
 
 #define RT_BOX_ID_LIMIT 1.0e18f
 RT_DEV float box_rcp(float d) {
-    float r = fminf(fmaxf(fast_rcp(d), -RT_BOX_ID_LIMIT), RT_BOX_ID_LIMIT);
-    return fabsf(r) >= 1.0e-30f ? r : copysignf(1.0e-30f, r); // never 0: an absent child's infinite planes must stay infinite
+    const float r = fast_rcp(d);
+    // magnitude clamped to [1e-30, 1e18] (never 0: an absent child's infinite planes must stay infinite), sign kept:
+    // one median and one bit-field insert; a NaN (from a NaN direction, rejected in trace_begin) would become 1e-30
+    return copysignf(__builtin_amdgcn_fmed3f(fabsf(r), 1.0e-30f, RT_BOX_ID_LIMIT), r);
 }
 // o, d, bound: the level's own space (world or object); ctr, inv_h: the frame of its packed nodes
 RT_DEV BoxRay make_box_ray(f3 o, f3 d, float bound, f3 ctr, f3 inv_h) {
