@@ -279,7 +279,7 @@ RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, S
                 const bool hit = intersect_triangle(S.rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, vn, wn, det);
                 const u32 prim_global = as_u32(c.y);
                 // closest hit, ties to the lowest (instance, primitive); written without short-circuit branches
-                const bool in_range = (t > tmin) & (t < tmax);
+                const bool in_range = t > tmin; // t < tmax follows from `better`: best.t starts at tmax and only decreases
                 const bool first_of_tie = (S.cur_inst < S.best.inst) | ((S.cur_inst == S.best.inst) & (prim_global < S.best.prim_global));
                 const bool better = (t < S.best.t) | (S.have_hit & (t == S.best.t) & first_of_tie);
                 if (hit & in_range & better) {
