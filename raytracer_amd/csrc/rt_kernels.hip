@@ -25,6 +25,10 @@ static constexpr int LDS_SIDE_ROW    = 17;  // row 16 is a dump row, rows 17-25 
 static constexpr int OVF_STACK_DEPTH = 48;  // global spill; 64 entries with the sentinel; the host checks tlas_depth + 1 + blas_depth <= 64
 static constexpr int BT = 256;
 static constexpr int SEG = 1024;            // rays per queue segment = threads per raygen / shade workgroup
+// seg_count[..][s] holds the fill of segment s; in the fused camera pass bit 31 says that the radiance of every ray in the
+// segment is +0 and was not stored (a path gathers radiance only where it ends, at a light -- unless a translucent
+// surface turns it into a NaN -- so this is the rule): 24 bytes per ray and bounce that neither shade moves
+static constexpr u32 SEG_RAD_ZERO = 0x80000000u, SEG_FILL_MASK = 0x7fffffffu;
 
 // per-lane traversal stack: the first LDS_STACK_DEPTH entries in LDS (entries of one lane are 64 dwords apart:
 // conflict-free), deeper entries in a global spill array indexed [entry][queue slot] (touched only by the rare deep
@@ -320,11 +324,11 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
             qi = seg * SEG + idx;
             if (task == 0) { // ray statistics: one wave sums the segment counts of this launch
                 u32 sum = 0;
-                for (u32 k = threadIdx.x; k < a.n_segments; k += TRAVERSE_WAVE) sum += a.seg_count[inq][k];
+                for (u32 k = threadIdx.x; k < a.n_segments; k += TRAVERSE_WAVE) sum += a.seg_count[inq][k] & SEG_FILL_MASK;
                 sum = wave_sum(sum);
                 if (threadIdx.x == 0) atomicAdd(a.probe ? &a.stats->rays_probe : &a.stats->rays_camera, (unsigned long long) sum);
             }
-            active = idx < a.seg_count[inq][seg];
+            active = idx < (a.seg_count[inq][seg] & SEG_FILL_MASK);
             if (active) {
                 const RayQueue& q = a.q[inq];
                 o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
@@ -387,7 +391,8 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             primary_ray(a, px, py, path, sample_index, rng, o, d);
         }
     } else {
-        active = threadIdx.x < a.seg_count[inq][blockIdx.x];
+        const u32 fill = a.seg_count[inq][blockIdx.x];
+        active = threadIdx.x < (fill & SEG_FILL_MASK);
         if (active) {
             const RayQueue& q = a.q[inq];
             path = q.path[qi];
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
                 const SlotState& st = a.st[inq];
                 if (!rng_dead) rng = st.rng[qi];
                 thr_prev = mk3(st.thr_x[qi], st.thr_y[qi], st.thr_z[qi]);
-                rad = mk3(st.rad_x[qi], st.rad_y[qi], st.rad_z[qi]);
+                if (!(fill & SEG_RAD_ZERO)) rad = mk3(st.rad_x[qi], st.rad_y[qi], st.rad_z[qi]);
             } else {
                 rng = a.ps.rng[path];
                 thr_prev = mk3(a.ps.thr_x[path], a.ps.thr_y[path], a.ps.thr_z[path]);
@@ -470,13 +475,14 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             const u32 key = (nd.x < 0.0f ? 1u : 0u) | (nd.y < 0.0f ? 2u : 0u) | (nd.z < 0.0f ? 4u : 0u);
             ls = block_rank_keyed(cont, key, s_cnt, total);
         } else ls = block_rank(cont, s_wave, total);
-        if (threadIdx.x == 0) a.seg_count[inq ^ 1u][blockIdx.x] = total;
+        const bool rad_zero = __syncthreads_or(cont && (as_u32(rad.x) | as_u32(rad.y) | as_u32(rad.z)) != 0u) == 0; // uniform
+        if (threadIdx.x == 0) a.seg_count[inq ^ 1u][blockIdx.x] = total | (rad_zero ? SEG_RAD_ZERO : 0u);
         if (cont) {
             s_stage[0][ls] = no.x; s_stage[1][ls] = no.y; s_stage[2][ls] = no.z;
             s_stage[3][ls] = nd.x; s_stage[4][ls] = nd.y; s_stage[5][ls] = nd.z; s_stage[6][ls] = __uint_as_float(path);
             s_stage[7][ls] = __uint_as_float(rng);
             s_stage[8][ls] = thr.x; s_stage[9][ls] = thr.y; s_stage[10][ls] = thr.z;
-            s_stage[11][ls] = rad.x; s_stage[12][ls] = rad.y; s_stage[13][ls] = rad.z;
+            if (!rad_zero) { s_stage[11][ls] = rad.x; s_stage[12][ls] = rad.y; s_stage[13][ls] = rad.z; }
         }
         __syncthreads();
         if (threadIdx.x < total) {
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             q.path[o2] = __float_as_uint(s_stage[6][t]);
             st.rng[o2] = __float_as_uint(s_stage[7][t]);
             st.thr_x[o2] = s_stage[8][t]; st.thr_y[o2] = s_stage[9][t]; st.thr_z[o2] = s_stage[10][t];
-            st.rad_x[o2] = s_stage[11][t]; st.rad_y[o2] = s_stage[12][t]; st.rad_z[o2] = s_stage[13][t];
+            if (!rad_zero) { st.rad_x[o2] = s_stage[11][t]; st.rad_y[o2] = s_stage[12][t]; st.rad_z[o2] = s_stage[13][t]; }
         }
         return; // the fused pass has no gather queue
     }
