@@ -342,8 +342,9 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
             TraceState S;
             trace_begin(a.scene, o, d, a.tmax, S);
             trace_run<LaneStack, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, S, cnt);
-            a.hits.t[qi] = S.best.t; a.hits.u[qi] = S.best.u; a.hits.v[qi] = S.best.v;
-            a.hits.inst[qi] = S.best.inst; a.hits.tri[qi] = S.best.tri;
+            // a miss is its instance field alone (-1): the other four words are neither written nor read (k_shade)
+            a.hits.inst[qi] = S.best.inst;
+            if (S.best.inst >= 0) { a.hits.t[qi] = S.best.t; a.hits.u[qi] = S.best.u; a.hits.v[qi] = S.best.v; a.hits.tri[qi] = S.best.tri; }
         }
         if (!PERSISTENT) break;
         task = next * TASK_PARTS + part < n_tasks ? next * TASK_PARTS + part : n_tasks;
@@ -412,7 +413,8 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
     }
     if (active) {
         HitOut h;
-        h.t = a.hits.t[qi]; h.u = a.hits.u[qi]; h.v = a.hits.v[qi]; h.inst = a.hits.inst[qi]; h.tri = a.hits.tri[qi];
+        h.inst = a.hits.inst[qi]; h.t = inf_f32(); h.u = 0.0f; h.v = 0.0f; h.tri = -1;
+        if (h.inst >= 0) { h.t = a.hits.t[qi]; h.u = a.hits.u[qi]; h.v = a.hits.v[qi]; h.tri = a.hits.tri[qi]; }
         h.prim_global = 0;
         float payload_t = a.probe ? inf_f32() : (float) bounce; // raytracing.hlsl:102-107
         shade_ray(a.shade, a.g, a.fudge, o, d, h, payload_t, rng, r, tail);
