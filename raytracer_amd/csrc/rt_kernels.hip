@@ -153,6 +153,10 @@ __global__ __launch_bounds__(BT) void k_camera_resolve(PassArgs a) {
     resolve_pixel(a, pixel, tot);
 }
 
+// one bit per thread of the bounce-0 shade, in the (otherwise unused) alpha array of the fused pass
+RT_DEV bool frame_miss_mask_in_use(const PassArgs& a) { return a.defer_resolve != 0 && a.g.samples_per_pixel == 1u && a.g.accumulator_count != 0u; }
+RT_DEV unsigned long long* frame_miss_mask(const PassArgs& a) { return (unsigned long long*) a.ps.alpha; }
+
 // pipelined frames (a.defer_resolve): the fused shades leave each pixel's sample sum in ps.sum_* and this kernel, the only
 // one of the frame that touches the accumulator, adds it in -- the frames' resolves run in frame order, everything else
 // of a frame overlaps its neighbours.  Same additions in the same order as the resolve inside k_shade.
@@ -160,6 +164,9 @@ __global__ __launch_bounds__(BT) void k_frame_resolve(PassArgs a) {
     u32 t = blockIdx.x * BT + threadIdx.x;
     u32 px, py;
     if (!thread_pixel(a, t, px, py)) return;
+    // pixels whose primary ray missed add (0, 0, 0, 0): nothing to do once the accumulator holds a frame (x + 0 is x, and
+    // the sums are never -0).  The bounce-0 shade, whose thread t has the same pixel, left one bit per thread.
+    if (frame_miss_mask_in_use(a) && ((frame_miss_mask(a)[t >> 6] >> (t & 63u)) & 1ull)) return;
     u32 pixel = py * a.width + px;
     float tot[4];
     if (a.g.samples_per_pixel == 1u) { // one 16-byte record per pixel (see k_shade)
@@ -365,7 +372,7 @@ template <bool PRIMARY, bool FUSED>
 __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounce, u32 sample_index) { // 8 waves per SIMD = two workgroups per CU: at most 64 VGPRs
     __shared__ u32 s_wave[SEG / 64];
     const u32 qi = blockIdx.x * SEG + threadIdx.x;
-    bool active, cont = false, gather = false;
+    bool active, cont = false, gather = false, zero_sample = false;
     u32 path = 0, rng = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
     f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
@@ -438,7 +445,8 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             if (sample_index + 1u < a.g.samples_per_pixel) {
                 a.ps.rng[path] = rng; // the next sample of this pixel continues the stream (raytracing.hlsl:130,141)
                 for (int k = 0; k < 4; k++) sum[k][path] = tot[k];
-            } else if (a.defer_resolve) { // k_frame_resolve adds it in
+            } else if (PRIMARY && missed_primary && frame_miss_mask_in_use(a)) zero_sample = true; // nothing to add: one bit for k_frame_resolve
+            else if (a.defer_resolve) { // k_frame_resolve adds it in
                 // with one sample per pixel nothing reads the four sum arrays as such: they are consecutive in the arena
                 // (rt_api.hip) and hold one float4 per pixel instead -- one 16-byte store, 128-byte runs per 8 pixels
                 if (a.g.samples_per_pixel == 1u) ((float4*) a.ps.sum_x)[path] = make_float4(tot[0], tot[1], tot[2], tot[3]);
@@ -459,6 +467,10 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             rec.t = h.inst < 0 ? inf_f32() : h.t; rec.u = h.u; rec.v = h.v; rec.rng_after = rng; rec.valid = 1u;
             a.capture[(size_t) bounce * a.width * a.height + path] = rec;
         }
+    }
+    if (PRIMARY && FUSED && frame_miss_mask_in_use(a)) { // uniform
+        const unsigned long long m = __ballot(zero_sample);
+        if ((threadIdx.x & 63u) == 0) frame_miss_mask(a)[qi >> 6] = m;
     }
     u32 total;
     if (tail) { // no path goes on: nothing to compact
