@@ -153,9 +153,18 @@ __global__ __launch_bounds__(BT) void k_camera_resolve(PassArgs a) {
     resolve_pixel(a, pixel, tot);
 }
 
-// one bit per thread of the bounce-0 shade, in the (otherwise unused) alpha array of the fused pass
-RT_DEV bool frame_miss_mask_in_use(const PassArgs& a) { return a.defer_resolve != 0 && a.g.samples_per_pixel == 1u && a.g.accumulator_count != 0u; }
+// Pipelined frames (a.defer_resolve) index their per-pixel state -- sample sums, RNG state between samples -- by the
+// thread of the bounce-0 kernels (tile-major: thread t <-> thread_pixel(t)) instead of by pixel: k_frame_resolve's thread
+// t reads record t, coalesced, and is the one that knows the pixel.
+// With one sample per pixel and a frame already in the accumulator, most pixels need no record at all.  Two bits per
+// thread, in the (otherwise unused) alpha array of the fused pass:
+//   miss    the primary ray missed: the sample is (0, 0, 0, 0) and adds nothing (x + 0 is x; the sums are never -0)
+//   record  the path ended with radiance: a float4 record holds the sample (set by the shade that ended it)
+//   neither the path ended dark: the sample is (0, 0, 0, 1), known without a record
+// The bounce-0 shade writes both words of its wave; later shades set `record` bits atomically.
+RT_DEV bool frame_masks_in_use(const PassArgs& a) { return a.defer_resolve != 0 && a.g.samples_per_pixel == 1u && a.g.accumulator_count != 0u; }
 RT_DEV unsigned long long* frame_miss_mask(const PassArgs& a) { return (unsigned long long*) a.ps.alpha; }
+RT_DEV unsigned long long* frame_record_mask(const PassArgs& a) { return (unsigned long long*) a.ps.alpha + (a.n_paths >> 4); } // halfway into the array
 
 // pipelined frames (a.defer_resolve): the fused shades leave each pixel's sample sum in ps.sum_* and this kernel, the only
 // one of the frame that touches the accumulator, adds it in -- the frames' resolves run in frame order, everything else
@@ -164,15 +173,15 @@ __global__ __launch_bounds__(BT) void k_frame_resolve(PassArgs a) {
     u32 t = blockIdx.x * BT + threadIdx.x;
     u32 px, py;
     if (!thread_pixel(a, t, px, py)) return;
-    // pixels whose primary ray missed add (0, 0, 0, 0): nothing to do once the accumulator holds a frame (x + 0 is x, and
-    // the sums are never -0).  The bounce-0 shade, whose thread t has the same pixel, left one bit per thread.
-    if (frame_miss_mask_in_use(a) && ((frame_miss_mask(a)[t >> 6] >> (t & 63u)) & 1ull)) return;
+    const bool masks = frame_masks_in_use(a);
+    if (masks && ((frame_miss_mask(a)[t >> 6] >> (t & 63u)) & 1ull)) return;
     u32 pixel = py * a.width + px;
-    float tot[4];
-    if (a.g.samples_per_pixel == 1u) { // one 16-byte record per pixel (see k_shade)
-        const float4 v = ((const float4*) a.ps.sum_x)[pixel];
+    float tot[4] = { 0.0f, 0.0f, 0.0f, 1.0f };
+    if (masks && !((frame_record_mask(a)[t >> 6] >> (t & 63u)) & 1ull)) { /* ended dark: (0, 0, 0, 1) */ }
+    else if (a.g.samples_per_pixel == 1u) { // one 16-byte record per thread (see k_shade)
+        const float4 v = ((const float4*) a.ps.sum_x)[t];
         tot[0] = v.x; tot[1] = v.y; tot[2] = v.z; tot[3] = v.w;
-    } else { tot[0] = a.ps.sum_x[pixel]; tot[1] = a.ps.sum_y[pixel]; tot[2] = a.ps.sum_z[pixel]; tot[3] = a.ps.sum_a[pixel]; }
+    } else { tot[0] = a.ps.sum_x[t]; tot[1] = a.ps.sum_y[t]; tot[2] = a.ps.sum_z[t]; tot[3] = a.ps.sum_a[t]; }
     resolve_pixel(a, pixel, tot);
 }
 
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
         if (PRIMARY) {
             u32 px, py;
             active = thread_pixel(a, qi, px, py);
-            if (active) { u32 rng; primary_ray(a, px, py, py * a.width + px, sample_index, rng, o, d); }
+            if (active) { u32 rng; primary_ray(a, px, py, a.defer_resolve ? qi : py * a.width + px, sample_index, rng, o, d); }
         } else {
             // queued launches take the waves of the segments "wave-major" (wave 0 of every segment, then wave 1, ...):
             // segments are compacted, so the empty waves behind their fill all land at the end of the launch instead of
@@ -372,7 +381,7 @@ template <bool PRIMARY, bool FUSED>
 __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounce, u32 sample_index) { // 8 waves per SIMD = two workgroups per CU: at most 64 VGPRs
     __shared__ u32 s_wave[SEG / 64];
     const u32 qi = blockIdx.x * SEG + threadIdx.x;
-    bool active, cont = false, gather = false, zero_sample = false;
+    bool active, cont = false, gather = false, zero_sample = false, record = false;
     u32 path = 0, rng = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
     f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
     if (PRIMARY) {
         u32 px = 0, py = 0;
         active = thread_pixel(a, qi, px, py);
-        path = py * a.width + px;
+        path = a.defer_resolve ? qi : py * a.width + px; // see frame_masks_in_use
         if (active) {
             if (!FUSED) { // per-dispatch sample sum (raytracing.hlsl:139-151), resolved by k_camera_resolve
                 if (sample_index == 0) {
@@ -445,8 +454,13 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             if (sample_index + 1u < a.g.samples_per_pixel) {
                 a.ps.rng[path] = rng; // the next sample of this pixel continues the stream (raytracing.hlsl:130,141)
                 for (int k = 0; k < 4; k++) sum[k][path] = tot[k];
-            } else if (PRIMARY && missed_primary && frame_miss_mask_in_use(a)) zero_sample = true; // nothing to add: one bit for k_frame_resolve
+            } else if (PRIMARY && missed_primary && frame_masks_in_use(a)) zero_sample = true; // nothing to add: one bit for k_frame_resolve
+            else if (!missed_primary && (as_u32(rad.x) | as_u32(rad.y) | as_u32(rad.z)) == 0u && frame_masks_in_use(a)) { /* ended dark: no record */ }
             else if (a.defer_resolve) { // k_frame_resolve adds it in
+                if (frame_masks_in_use(a)) {
+                    if (PRIMARY) record = true; // goes out with the wave's word below
+                    else atomicOr(frame_record_mask(a) + (path >> 6), 1ull << (path & 63u));
+                }
                 // with one sample per pixel nothing reads the four sum arrays as such: they are consecutive in the arena
                 // (rt_api.hip) and hold one float4 per pixel instead -- one 16-byte store, 128-byte runs per 8 pixels
                 if (a.g.samples_per_pixel == 1u) ((float4*) a.ps.sum_x)[path] = make_float4(tot[0], tot[1], tot[2], tot[3]);
@@ -468,9 +482,9 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             a.capture[(size_t) bounce * a.width * a.height + path] = rec;
         }
     }
-    if (PRIMARY && FUSED && frame_miss_mask_in_use(a)) { // uniform
-        const unsigned long long m = __ballot(zero_sample);
-        if ((threadIdx.x & 63u) == 0) frame_miss_mask(a)[qi >> 6] = m;
+    if (PRIMARY && FUSED && frame_masks_in_use(a)) { // uniform
+        const unsigned long long m = __ballot(zero_sample), rec = __ballot(record);
+        if ((threadIdx.x & 63u) == 0) { frame_miss_mask(a)[qi >> 6] = m; frame_record_mask(a)[qi >> 6] = rec; }
     }
     u32 total;
     if (tail) { // no path goes on: nothing to compact
