@@ -157,7 +157,9 @@ def main():
         del scratch
     # every 8th frame of the timed region has its traverse / gather launches bracketed by HIP events on the library's
     # stream (bracketing all of them costs 13 us of a 0.28 ms frame in event packets)
-    rt.set_flags(scene.flags | _abi.RT_FLAG_TIME_KERNELS | _abi.RT_FLAG_TIME_SAMPLED)
+    # (a short run times every frame, so that it has launches to report at all)
+    timing_flags = _abi.RT_FLAG_TIME_KERNELS | (_abi.RT_FLAG_TIME_SAMPLED if args.steps >= 16 else 0)
+    rt.set_flags(scene.flags | timing_flags)
     rt.reset_stats()
 
     def fence():
@@ -213,7 +215,7 @@ def main():
                 n1 = max(8, min(args.steps, 48))
                 chain1 = distributed.FrameChain(scene.globals.frame_rng)
                 for k in range(2): distributed.render_frame(rt1, scene.globals, k, chain1)
-                rt1.set_flags(scene.flags | _abi.RT_FLAG_TIME_KERNELS | _abi.RT_FLAG_TIME_SAMPLED)
+                rt1.set_flags(scene.flags | _abi.RT_FLAG_TIME_KERNELS | (_abi.RT_FLAG_TIME_SAMPLED if n1 >= 16 else 0))
                 rt1.sync(); rt1.reset_stats()
                 t1 = time.perf_counter()
                 for k in range(n1): distributed.render_frame(rt1, scene.globals, 2 + k, chain1)
