@@ -113,6 +113,7 @@ struct rt_ctx {
     uint64_t traverse_launches = 0, gather_launches = 0, primary_rays = 0, traverse_launches_timed = 0, gather_launches_timed = 0;
     uint64_t dispatch_index = 0; // rt_dispatch_rays calls so far (RT_FLAG_TIME_SAMPLED times every 8th)
     double blas_build_ms = 0, tlas_build_ms = 0; uint64_t blas_triangles = 0;
+    hipEvent_t build_ev[2] = { nullptr, nullptr }; // bracket the builds of rt_build_blas / rt_build_tlas (created once: no error path can leak them)
     rt_ctx() { memset(&g, 0, sizeof g); memset(q, 0, sizeof q); memset(&hits, 0, sizeof hits); memset(&ps, 0, sizeof ps); memset(st, 0, sizeof st); memset(&gq, 0, sizeof gq); memset(&alt, 0, sizeof alt); }
 };
 
@@ -366,6 +367,17 @@ int run_pass(rt_ctx* c, bool probe) {
     return fused ? launch_frame_resolve(c->stream, a) : launch_camera_resolve(c->stream, a);
 }
 
+// the hierarchical gather dropped part of a walk (DeviceStats::hg_overflow): results since the last check are wrong
+int check_gather_overflow(rt_ctx* c) {
+    if (!(c->hg_enabled && c->hg_built)) return RT_OK;
+    unsigned long long flag = 0;
+    RT_HIP(hipMemcpy(&flag, &c->d_stats->hg_overflow, sizeof flag, hipMemcpyDeviceToHost));
+    if (!flag) return RT_OK;
+    RT_HIP(hipMemset(&c->d_stats->hg_overflow, 0, sizeof flag));
+    set_error("hierarchical gather: a walk overflowed its %d-entry stack; the frames since the last check are incomplete", 24);
+    return RT_ERR_LIMIT;
+}
+
 float triangle_area(const float* a, const float* b, const float* c) { // geometry.cpp:21-25
     float e1[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] }, e2[3] = { c[0] - a[0], c[1] - a[1], c[2] - a[2] };
     float cr[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
@@ -385,12 +397,69 @@ void phase_sequence(u32 seed, u32 count, u32* seq) {
     }
 }
 
+
+void free_blas(Blas& b) {
+    dev_free(b.d_verts); dev_free(b.d_indices); dev_free(b.d_geoms); dev_free(b.d_tri_geometry);
+    dev_free(b.d_nodes); b.d_tris = nullptr; dev_free(b.d_perm);
+}
+
+// device half of rt_build_blas: uploads the concatenated geometry and builds the bottom-level tree on c->stream
+int build_blas_on_device(rt_ctx* c, Blas& b, const std::vector<u32>& tri_geometry) {
+    u32 n_nodes = b.n_tris > 1 ? b.n_tris - 1 : 1;
+    RT_HIP(hipMalloc(&b.d_verts, b.verts.size() * sizeof(RtVertex)));
+    RT_HIP(hipMalloc(&b.d_indices, b.indices.size() * sizeof(uint16_t)));
+    RT_HIP(hipMalloc(&b.d_geoms, b.geoms.size() * sizeof(GeomRec)));
+    RT_HIP(hipMalloc(&b.d_tri_geometry, tri_geometry.size() * 4));
+    // nodes and triangles share one allocation: an instance record addresses both with one pointer + a 32-bit offset
+    RT_HIP(hipMalloc(&b.d_nodes, n_nodes * sizeof(PackedNode) + 3 * (size_t) b.n_tris * sizeof(TriRec))); // three copies of the triangles (TriRec)
+    b.d_tris = (TriRec*) (b.d_nodes + n_nodes);
+    RT_HIP(hipMalloc(&b.d_perm, b.n_tris * 4));
+    RT_HIP(hipMemcpyAsync(b.d_verts, b.verts.data(), b.verts.size() * sizeof(RtVertex), hipMemcpyHostToDevice, c->stream));
+    RT_HIP(hipMemcpyAsync(b.d_indices, b.indices.data(), b.indices.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    RT_HIP(hipMemcpyAsync(b.d_geoms, b.geoms.data(), b.geoms.size() * sizeof(GeomRec), hipMemcpyHostToDevice, c->stream));
+    RT_HIP(hipMemcpyAsync(b.d_tri_geometry, tri_geometry.data(), tri_geometry.size() * 4, hipMemcpyHostToDevice, c->stream));
+    int rc = lbvh_workspace_reserve(c->lbvh, b.n_tris); if (rc) return rc;
+    RT_HIP(hipEventRecord(c->build_ev[0], c->stream));
+    rc = lbvh_triangle_boxes(c->stream, c->lbvh, b.d_verts, b.d_indices, b.n_tris); if (rc) return rc;
+    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, b.n_tris, RT_LEAF_MAX_TRIS, false, b.d_nodes, b.d_perm); if (rc) return rc;
+    rc = lbvh_write_trirecs(c->stream, b.d_perm, b.d_verts, b.d_indices, b.d_tri_geometry, b.d_geoms, b.n_tris, b.d_tris); if (rc) return rc;
+    RT_HIP(hipEventRecord(c->build_ev[1], c->stream));
+    RT_HIP(hipMemcpyAsync(&b.info, c->lbvh.tree_info, sizeof b.info, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(hipStreamSynchronize(c->stream)); // host arrays are borrowed only for this call
+    float ms = 0; RT_HIP(hipEventElapsedTime(&ms, c->build_ev[0], c->build_ev[1]));
+    c->blas_build_ms = ms;
+    return RT_OK;
+}
+
 } // namespace
 
 extern "C" {
 
 const char* rt_last_error(void) { return g_error; }
 int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+namespace {
+int create_context(rt_ctx* c) {
+    if (const char* v = getenv("RT_BVH_BUILDER")) c->bvh_builder = atoi(v);
+    if (const char* v = getenv("RT_SAH_TRI")) c->sah_tri = (float) atof(v);
+    if (const char* v = getenv("RT_RAY_SORT")) c->ray_sort = atoi(v);
+    if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
+    if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
+    if (const char* v = getenv("RT_FRAMES_IN_FLIGHT")) c->frames_in_flight = atoi(v);
+    if (const char* v = getenv("RT_EXACT_INSTANCE_BOXES")) c->exact_instance_boxes = atoi(v) != 0;
+    hipDeviceProp_t prop;
+    RT_HIP(hipGetDeviceProperties(&prop, c->device));
+    c->persistent_slots = (u32) prop.multiProcessorCount * 4u * 5u;
+    RT_HIP(hipMalloc(&c->d_task_counter, 65 * 128));
+    RT_HIP(hipMemset(c->d_task_counter, 0, 65 * 128));
+    RT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    RT_HIP(hipMalloc(&c->d_stats, sizeof(DeviceStats)));
+    RT_HIP(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
+    for (int k = 0; k < 2; k++) RT_HIP(hipEventCreate(&c->build_ev[k]));
+    return RT_OK;
+}
+} // namespace
 
 int rt_create(const int* devices, int n, rt_ctx** out) {
     if (!out || !devices || n < 1) { set_error("rt_create: bad arguments"); return RT_ERR_INVALID; }
@@ -402,24 +471,8 @@ int rt_create(const int* devices, int n, rt_ctx** out) {
     RT_HIP(hipSetDevice(devices[0]));
     rt_ctx* c = new rt_ctx();
     c->device = devices[0];
-    if (const char* v = getenv("RT_BVH_BUILDER")) c->bvh_builder = atoi(v);
-    if (const char* v = getenv("RT_SAH_TRI")) c->sah_tri = (float) atof(v);
-    if (const char* v = getenv("RT_RAY_SORT")) c->ray_sort = atoi(v);
-    if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
-    if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
-    if (const char* v = getenv("RT_FRAMES_IN_FLIGHT")) c->frames_in_flight = atoi(v);
-    {
-        hipDeviceProp_t prop;
-        RT_HIP(hipGetDeviceProperties(&prop, c->device));
-        c->persistent_slots = (u32) prop.multiProcessorCount * 4u * 5u;
-        RT_HIP(hipMalloc(&c->d_task_counter, 65 * 128));
-        RT_HIP(hipMemset(c->d_task_counter, 0, 65 * 128));
-    }
-    if (const char* v = getenv("RT_EXACT_INSTANCE_BOXES")) c->exact_instance_boxes = atoi(v) != 0;
-    RT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    RT_HIP(hipMalloc(&c->d_stats, sizeof(DeviceStats)));
-    RT_HIP(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
+    int rc = create_context(c);
+    if (rc != RT_OK) { rt_destroy(c); return rc; } // frees whatever the failed set-up had already made
     *out = c;
     return RT_OK;
 }
@@ -428,16 +481,13 @@ void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void) hipSetDevice(c->device);
     (void) quiesce(c);
-    (void) hipStreamSynchronize(c->stream);
-    drain_timers(c);
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
+    (void) drain_timers(c);
     dev_free(c->alt.d_arena); dev_free(c->alt.d_seg_count);
     if (c->alt_stream) (void) hipStreamDestroy(c->alt_stream);
     for (int k = 0; k < 2; k++) if (c->lane_done[k]) (void) hipEventDestroy(c->lane_done[k]);
     for (int k = 0; k < 2; k++) if (c->probe_done[k]) (void) hipEventDestroy(c->probe_done[k]);
-    for (auto& b : c->blas) {
-        dev_free(b.d_verts); dev_free(b.d_indices); dev_free(b.d_geoms); dev_free(b.d_tri_geometry);
-        dev_free(b.d_nodes); b.d_tris = nullptr; dev_free(b.d_perm);
-    }
+    for (auto& b : c->blas) free_blas(b);
     for (auto& m : c->translucent_meshes) dev_free(m.d_partial_areas);
     free_sample_points(c);
     dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
@@ -445,6 +495,7 @@ void rt_destroy(rt_ctx* c) {
     dev_free(c->d_accumulator); dev_free(c->d_render_target); dev_free(c->d_capture); dev_free(c->d_arena);
     dev_free(c->d_seg_count); dev_free(c->d_stats); dev_free(c->d_table[0]); dev_free(c->d_table[1]);
     lbvh_workspace_free(c->lbvh); ploc_workspace_free(c->ploc); sah_workspace_free(c->sah);
+    for (int k = 0; k < 2; k++) if (c->build_ev[k]) (void) hipEventDestroy(c->build_ev[k]);
     if (c->own_stream) (void) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -458,7 +509,8 @@ int rt_set_stream(rt_ctx* c, void* s) {
 }
 
 int rt_update_resolution(rt_ctx* c, uint32_t w, uint32_t h) {
-    if (!c || w == 0 || h == 0 || (uint64_t) w * h > (1ull << 28)) { set_error("rt_update_resolution: bad size"); return RT_ERR_INVALID; }
+    // each side <= 32768 keeps tiles * 1024 queue slots (and every pixel index) inside 32 bits
+    if (!c || w == 0 || h == 0 || w > 32768u || h > 32768u || (uint64_t) w * h > (1ull << 28)) { set_error("rt_update_resolution: bad size %ux%u (each side <= 32768, at most 2^28 pixels)", w, h); return RT_ERR_INVALID; }
     RT_HIP(hipSetDevice(c->device));
     { int rc = quiesce(c); if (rc) return rc; }
     RT_HIP(hipStreamSynchronize(c->stream));
@@ -519,7 +571,8 @@ int rt_build_blas(rt_ctx* c, const RtGeometry* geometries, int n, rt_blas* out) 
     }
     if (b.verts.size() > 65535) { set_error("rt_build_blas: %zu vertices exceed the 16-bit index range", b.verts.size()); return RT_ERR_LIMIT; } // raytracing.cpp:367
     b.n_tris = (u32) b.indices.size() / 3;
-    if (b.n_tris == 0 || b.n_tris >= (1u << 27)) { set_error("rt_build_blas: bad triangle count %u", b.n_tris); return RT_ERR_INVALID; }
+    // InstRec addresses the three TriRec copies with 32-bit byte offsets: nodes + 3 copies must stay below 4 GiB
+    if (b.n_tris == 0 || b.n_tris > (1u << 24)) { set_error("rt_build_blas: bad triangle count %u (limit %u)", b.n_tris, 1u << 24); return RT_ERR_LIMIT; }
     int blas_index = (int) c->blas.size();
     // translucent geometries, raytracing.cpp:377-398 + Bluenoise::preprocess_mesh_data, bluenoise.cpp:69-93
     std::vector<TranslucentMesh> new_meshes;
@@ -543,38 +596,24 @@ int rt_build_blas(rt_ctx* c, const RtGeometry* geometries, int n, rt_blas* out) 
             }
         }
         if (!partial.empty()) {
-            RT_HIP(hipMalloc(&m.d_partial_areas, partial.size() * 4));
-            RT_HIP(hipMemcpy(m.d_partial_areas, partial.data(), partial.size() * 4, hipMemcpyHostToDevice));
+            hipError_t e = hipMalloc(&m.d_partial_areas, partial.size() * 4);
+            if (e == hipSuccess) e = hipMemcpy(m.d_partial_areas, partial.data(), partial.size() * 4, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                set_error("rt_build_blas: area table upload failed: %s", hipGetErrorString(e));
+                dev_free(m.d_partial_areas);
+                for (auto& done : new_meshes) dev_free(done.d_partial_areas);
+                return RT_ERR_DEVICE;
+            }
         }
         new_meshes.push_back(m);
     }
-    // upload + build
-    hipEvent_t e0, e1;
-    RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
-    u32 n_nodes = b.n_tris > 1 ? b.n_tris - 1 : 1;
-    RT_HIP(hipMalloc(&b.d_verts, b.verts.size() * sizeof(RtVertex)));
-    RT_HIP(hipMalloc(&b.d_indices, b.indices.size() * sizeof(uint16_t)));
-    RT_HIP(hipMalloc(&b.d_geoms, b.geoms.size() * sizeof(GeomRec)));
-    RT_HIP(hipMalloc(&b.d_tri_geometry, tri_geometry.size() * 4));
-    // nodes and triangles share one allocation: an instance record addresses both with one pointer + a 32-bit offset
-    RT_HIP(hipMalloc(&b.d_nodes, n_nodes * sizeof(PackedNode) + 3 * (size_t) b.n_tris * sizeof(TriRec))); // three copies of the triangles (TriRec)
-    b.d_tris = (TriRec*) (b.d_nodes + n_nodes);
-    RT_HIP(hipMalloc(&b.d_perm, b.n_tris * 4));
-    RT_HIP(hipMemcpyAsync(b.d_verts, b.verts.data(), b.verts.size() * sizeof(RtVertex), hipMemcpyHostToDevice, c->stream));
-    RT_HIP(hipMemcpyAsync(b.d_indices, b.indices.data(), b.indices.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-    RT_HIP(hipMemcpyAsync(b.d_geoms, b.geoms.data(), b.geoms.size() * sizeof(GeomRec), hipMemcpyHostToDevice, c->stream));
-    RT_HIP(hipMemcpyAsync(b.d_tri_geometry, tri_geometry.data(), tri_geometry.size() * 4, hipMemcpyHostToDevice, c->stream));
-    int rc = lbvh_workspace_reserve(c->lbvh, b.n_tris); if (rc) return rc;
-    RT_HIP(hipEventRecord(e0, c->stream));
-    rc = lbvh_triangle_boxes(c->stream, c->lbvh, b.d_verts, b.d_indices, b.n_tris); if (rc) return rc;
-    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, b.n_tris, RT_LEAF_MAX_TRIS, false, b.d_nodes, b.d_perm); if (rc) return rc;
-    rc = lbvh_write_trirecs(c->stream, b.d_perm, b.d_verts, b.d_indices, b.d_tri_geometry, b.d_geoms, b.n_tris, b.d_tris); if (rc) return rc;
-    RT_HIP(hipEventRecord(e1, c->stream));
-    RT_HIP(hipMemcpyAsync(&b.info, c->lbvh.tree_info, sizeof b.info, hipMemcpyDeviceToHost, c->stream));
-    RT_HIP(hipStreamSynchronize(c->stream)); // host arrays are borrowed only for this call
-    float ms = 0; RT_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
-    c->blas_build_ms = ms;
+    // upload + build; a failure frees everything this call allocated
+    int rc = build_blas_on_device(c, b, tri_geometry);
+    if (rc != RT_OK) {
+        free_blas(b);
+        for (auto& m : new_meshes) dev_free(m.d_partial_areas);
+        return rc;
+    }
     b.depth = b.info.depth;
     c->blas_triangles += b.n_tris;
     for (auto& m : new_meshes) { c->translucent_meshes.push_back(m); c->translucent_mean_area.push_back(0.0f); }
@@ -622,6 +661,7 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
         max_blas_depth = std::max(max_blas_depth, b.depth);
     }
     dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
+    c->n_instances = 0; c->tlas_depth = 0; // no top level until this call has succeeded: a failure below leaves rt_dispatch_rays answering RT_ERR_STATE
     u32 n_nodes = n > 1 ? (u32) n - 1 : 1;
     RT_HIP(hipMalloc(&c->d_inst_rec, sizeof(InstRec) * n));
     RT_HIP(hipMalloc(&c->d_inst_shade, sizeof(InstShade) * n));
@@ -630,25 +670,21 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
     RT_HIP(hipMemcpyAsync(c->d_inst_rec, rec.data(), sizeof(InstRec) * n, hipMemcpyHostToDevice, c->stream));
     RT_HIP(hipMemcpyAsync(c->d_inst_shade, shade.data(), sizeof(InstShade) * n, hipMemcpyHostToDevice, c->stream));
     int rc = lbvh_workspace_reserve(c->lbvh, (u32) n); if (rc) return rc;
-    hipEvent_t e0, e1;
-    RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
-    RT_HIP(hipEventRecord(e0, c->stream));
+    RT_HIP(hipEventRecord(c->build_ev[0], c->stream));
     const bool exact_boxes = c->exact_instance_boxes && vertex_work <= (4ull << 30);
     rc = lbvh_instance_boxes(c->stream, c->lbvh, c->d_inst_shade, c->d_inst_rec, (u32) n, exact_boxes); if (rc) return rc;
     rc = lbvh_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, (u32) n, 1, true, c->d_tlas_nodes, c->d_tlas_perm); if (rc) return rc;
-    RT_HIP(hipEventRecord(e1, c->stream));
+    RT_HIP(hipEventRecord(c->build_ev[1], c->stream));
     RT_HIP(hipMemcpyAsync(&c->tlas_info, c->lbvh.tree_info, sizeof c->tlas_info, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
-    float ms = 0; RT_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    float ms = 0; RT_HIP(hipEventElapsedTime(&ms, c->build_ev[0], c->build_ev[1]));
     c->tlas_build_ms = ms;
-    c->tlas_depth = c->tlas_info.depth;
-    c->n_instances = (u32) n;
-    if (c->tlas_depth + 1 + max_blas_depth > 64) {
-        set_error("rt_build_tlas: BVH too deep for the traversal stack (tlas %d + blas %d)", c->tlas_depth, max_blas_depth);
-        c->n_instances = 0;
+    if (c->tlas_info.depth + 1 + max_blas_depth > 64) {
+        set_error("rt_build_tlas: BVH too deep for the traversal stack (tlas %d + blas %d)", c->tlas_info.depth, max_blas_depth);
         return RT_ERR_LIMIT;
     }
+    c->tlas_depth = c->tlas_info.depth;
+    c->n_instances = (u32) n;
     return RT_OK;
 }
 
@@ -954,7 +990,7 @@ int rt_sync(rt_ctx* c) {
     if (!c) return RT_ERR_INVALID;
     { int rc = quiesce(c); if (rc) return rc; }
     RT_HIP(hipStreamSynchronize(c->stream));
-    return RT_OK;
+    return check_gather_overflow(c);
 }
 
 int rt_read_accumulator(rt_ctx* c, float* rgba) {
@@ -962,7 +998,7 @@ int rt_read_accumulator(rt_ctx* c, float* rgba) {
     { int qrc = quiesce(c); if (qrc) return qrc; }
     RT_HIP(hipMemcpyAsync(rgba, c->d_accumulator, (size_t) c->width * c->height * 16, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
-    return RT_OK;
+    return check_gather_overflow(c);
 }
 int rt_read_render_target(rt_ctx* c, uint8_t* rgba8) {
     if (!c || !rgba8 || !c->d_render_target) return RT_ERR_INVALID;

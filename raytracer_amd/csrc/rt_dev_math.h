@@ -5,16 +5,16 @@
 // are reproducible bit for bit; see DESIGN.md "Arithmetic contract" S1..S9.  Citations are file:line in the
 // reference tree (gluyas/raytracer).
 //
-// The functions are RT_DEV so that the header also parses in hipcc's host pass; the product only ever runs them
-// on the GPU.
+// Device code only: the header is compiled by hipcc alone (its host pass merely parses it).
 #pragma once
 #include <stdint.h>
 #include <math.h>
 #include <string.h>
 
-#if defined(__HIPCC__)
-#define RT_DEV __device__ __forceinline__
+#if !defined(__HIPCC__)
+#error "rt_dev_math.h holds gfx950 device code: compile with hipcc"
 #endif
+#define RT_DEV __device__ __forceinline__
 #if defined(__HIP_DEVICE_COMPILE__)
 // explicit address spaces: pointers that were loaded from memory (instance records) or merged in a phi are "flat" to
 // the compiler, and flat_load/flat_store are slower than global_load / ds_read and serialise the wait counters
@@ -23,9 +23,6 @@
 #else
 #define RT_GLOBAL
 #define RT_LDS
-#endif
-#if !defined(__HIPCC__)
-#define RT_DEV inline
 #endif
 
 namespace rtd {
@@ -252,18 +249,10 @@ RT_DEV float dipole_eval(const DipoleConst& c, float radius) {
 // Hardware approximations (1-2 ulp), used only where the result is covered by a tolerance and never decides a hit id
 // or an RNG draw: the conservative box test and the BSSRDF gather (radiance, 1e-4).
 RT_DEV float fast_rcp(float x) {
-#if defined(__HIPCC__)
     return __builtin_amdgcn_rcpf(x);
-#else
-    return 1.0f / x;
-#endif
 }
 RT_DEV float fast_sqrt(float x) {
-#if defined(__HIPCC__)
     return __builtin_amdgcn_sqrtf(x);
-#else
-    return sqrtf(x);
-#endif
 }
 // x / y where the caller supplies inv_y = 1 / y (IEEE) of a divisor shared by many quotients: one Newton step on the
 // product.  Three instructions instead of the ~11 of a division; equals the correctly rounded quotient except in rare
@@ -276,32 +265,20 @@ RT_DEV float div_by_shared(float x, float y, float inv_y) {
 // sqrt(x), x >= 0 and normal: hardware reciprocal square root refined by one Heron step (5 instructions instead of
 // the ~12 of the correctly rounded library sequence); at most 1 ulp off, exact for 0
 RT_DEV float sqrt_refined(float x) {
-#if defined(__HIPCC__)
     float y = __builtin_amdgcn_rsqf(x);
     float s = x * y, h = 0.5f * y;
     float r = __builtin_fmaf(-s, s, x);
     float t = __builtin_fmaf(r, h, s);
     return x > 0.0f ? t : 0.0f;
-#else
-    return sqrtf(x);
-#endif
 }
 RT_DEV float fast_exp(float x) {
-#if defined(__HIPCC__)
     return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
-#else
-    return expf(x);
-#endif
 }
 // dipole_eval with hardware rcp / exp2 and exp(-sigma (r + z)) split as exp(-sigma r) exp(-sigma z), so that both poles
 // share one exponential per pair and the per-pole factors come from dipole_constants: the same function to a few ulp
 RT_DEV float dipole_eval_fast(const DipoleConst& c, float radius) {
     float ir = fast_rcp(radius + c.z_real), iv = fast_rcp(radius + c.z_virtual);
-#if defined(__HIPCC__)
     float e = __builtin_amdgcn_exp2f(radius * c.exp2_rate);
-#else
-    float e = expf(-c.sigma_tr * radius);
-#endif
     float m_real = (c.sigma_tr + ir) * (ir * ir);
     float m_virtual = (c.sigma_tr + iv) * (iv * iv);
     float r = e * (c.a_real * m_real + c.a_virtual * m_virtual);

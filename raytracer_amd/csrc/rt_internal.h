@@ -122,6 +122,7 @@ struct HgView {
 
 struct DeviceStats { // lives in device memory
     unsigned long long rays_camera, rays_probe, gather_pairs, nodes, tris, insts, node_trips, tri_trips, inst_trips, max_ray_steps;
+    unsigned long long hg_overflow; // k_gather_hg ran out of walk stack and dropped a subtree: the host reports RT_ERR_LIMIT (rt_sync, rt_get_stats, reads)
 };
 
 struct PassArgs {

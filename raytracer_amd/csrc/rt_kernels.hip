@@ -828,7 +828,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather_hg(PassArgs a) {
         } else if (sp + 2 <= HG_STACK) {
             stack[(sp++) * GATHER_BLOCK] = n.right;
             stack[(sp++) * GATHER_BLOCK] = id + 1u;
-        }
+        } else a.stats->hg_overflow = 1ull; // cannot happen while the host's depth check holds (hg_build_all); never silently
     }
     E = E / (float) (a.g.translucent_accumulator_count + 1u);                                           // :332
     f3 emission = E * g.tf[i] / (RT_TAU_F / 2.0f);                                                     // :347

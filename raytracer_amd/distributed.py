@@ -9,7 +9,10 @@ allows without changing any pixel's sample stream:
                       W*H*spp camera paths, and replication keeps sample-point payloads bit-identical without an exchange.
   sample split  (C5)  rank r renders frames r, r+world, ... of the frame_rng chain (main.cpp:443-454) into its own
                       accumulator; one reduce(sum) of the RGBA32F buffer at the end.  Equal to the sequential sum up to
-                      float re-association.
+                      float re-association -- for scenes WITHOUT translucent sample points: the sample-point payloads are
+                      a running sum over all earlier frames (raytracing.hlsl:243-263), which a rank that skips frames does
+                      not have (require_no_sample_points).  After the reduce the 8-bit image is resolved with the TOTAL
+                      frame count (resolve_reduced), not the rank's own.
 """
 import numpy as np
 
@@ -52,6 +55,24 @@ def render_frame(backend, base_globals, frame, seed0):
 
 def sample_split_frames(rank, world, total_frames):
     return list(range(rank, total_frames, world))
+
+
+def require_no_sample_points(backend):
+    """The sample-set split is only equal to the sequential render when no frame depends on the frames before it:
+    scenes with translucent sample points (probe payloads accumulate frame by frame) must use the tile split."""
+    n = sum(backend.sample_point_count(i) for i in range(backend.translucent_instance_count()))
+    if n:
+        raise ValueError("sample-set split: the scene has %d translucent sample points whose payloads accumulate over "
+                         "consecutive frames; use the tile split (set_tile_split) for it" % n)
+
+
+def resolve_reduced(backend, total_frames):
+    """raytracing.hlsl:161 on an accumulator that now holds `total_frames` frames (after the reduce over ranks): the
+    rank's own accumulator_count is one rank's share, so the count is set before the resolve."""
+    g = backend.get_globals()
+    g.accumulator_count = int(total_frames)
+    backend.set_globals(g)
+    backend.resolve_render_target()
 
 
 def device_accumulator(rt, device):
