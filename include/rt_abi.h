@@ -208,6 +208,16 @@ int  rt_set_gather_mode(rt_ctx* ctx, int hierarchical, float max_solid_angle);
  * hierarchical gather, or a stream set by rt_set_stream): every other call waits for both. */
 int  rt_dispatch_rays(rt_ctx* ctx);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory -- code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc: the frame of rt_dispatch_rays, one at a time on the context's
+ * stream (rt_set_stream's, if set), with every scratch buffer (ray queues, hit records, path state, segment counters,
+ * traversal-stack overflow) in a 27.5 MB static device array instead of buffers allocated on demand.  Calls no
+ * hipMalloc / hipFree / event or stream creation.  Limits: at most 64 tiles of 32x32 pixels (e.g. 256x256) and 65,536
+ * sample points, else RT_ERR_LIMIT; RT_FLAG_CAPTURE_HITS / RT_FLAG_TIME_KERNELS give RT_ERR_UNSUPPORTED (they
+ * allocate).  Same results as rt_dispatch_rays, bit for bit.  All contexts on one GPU share the array: calls that
+ * overlap on one GPU (two contexts, or two streams) race. */
+int  rt_dispatch_rays_static(rt_ctx* ctx);
+
 /* ---- synchronisation and read-back -------------------------------------------------------------------- */
 int  rt_sync(rt_ctx* ctx);
 int  rt_read_accumulator(rt_ctx* ctx, float* rgba);           /* g_sample_accumulator, W*H*4 floats; blocks */

@@ -181,6 +181,9 @@ class Backend(object):
     def dispatch_rays(self):
         self._call("dispatch_rays")
 
+    def dispatch_rays_static(self):
+        self._call("dispatch_rays_static")
+
     def read_accumulator(self):
         out = np.empty((self.height, self.width, 4), dtype=np.float32)
         self._call("read_accumulator", C.c_void_p(out.ctypes.data))

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 
 using namespace rtd;
 using namespace rti;
@@ -113,6 +114,7 @@ struct rt_ctx {
     uint64_t traverse_launches = 0, gather_launches = 0, primary_rays = 0, traverse_launches_timed = 0, gather_launches_timed = 0;
     uint64_t dispatch_index = 0; // rt_dispatch_rays calls so far (RT_FLAG_TIME_SAMPLED times every 8th)
     double blas_build_ms = 0, tlas_build_ms = 0; uint64_t blas_triangles = 0;
+    void* d_static_scratch = nullptr; // this GPU's copy of the static scratch array of rt_dispatch_rays_static (resolved at rt_create)
     hipEvent_t build_ev[2] = { nullptr, nullptr }; // bracket the builds of rt_build_blas / rt_build_tlas (created once: no error path can leak them)
     rt_ctx() { memset(&g, 0, sizeof g); memset(q, 0, sizeof q); memset(&hits, 0, sizeof hits); memset(&ps, 0, sizeof ps); memset(st, 0, sizeof st); memset(&gq, 0, sizeof gq); memset(&alt, 0, sizeof alt); }
 };
@@ -141,15 +143,17 @@ void swap_path_buffers(rt_ctx* c) {
     for (int k = 0; k < 2; k++) { std::swap(c->q[k], o.q[k]); std::swap(c->st[k], o.st[k]); }
 }
 
-// allocates the current set of path buffers for `segs` segments of 1024 queue slots
-int alloc_path_buffers(rt_ctx* c, u32 segs) {
-    u32 need = segs * 1024; // queue slots; path-state arrays are indexed by pixel / point id < need
-    RT_HIP(hipMalloc(&c->d_seg_count, sizeof(u32) * (4 * (size_t) segs + 1))); // 2 queues, gather, gather offsets
-    RT_HIP(hipMemset(c->d_seg_count, 0, sizeof(u32) * (4 * (size_t) segs + 1)));
-    const int n_arrays = 14 /* 2 queues x (6 + path) */ + 5 /* hits */ + 15 /* path state */ + 14 /* slot state x 2 */ + 9 /* gather */ + 48 /* stack spill */;
-    size_t stride = ((size_t) need + 63) & ~(size_t) 63;
-    RT_HIP(hipMalloc(&c->d_arena, stride * 4 * n_arrays));
-    float* p = c->d_arena;
+// float arrays of one set of path buffers: 2 queues x (6 + path), hits, path state, slot state x 2, gather queue, stack spill
+constexpr int PATH_ARRAYS = 14 + 5 + 15 + 14 + 9 + 48;
+size_t path_stride(u32 segs) { return ((size_t) segs * 1024 + 63) & ~(size_t) 63; }
+size_t seg_count_words(u32 segs) { return 4 * (size_t) segs + 1; } // 2 queues, gather, gather offsets
+
+// points the context's current set of path buffers into `arena` (PATH_ARRAYS * path_stride(segs) floats) and
+// `seg_count` (seg_count_words(segs) words)
+void carve_path_buffers(rt_ctx* c, float* arena, u32* seg_count, u32 segs) {
+    const size_t stride = path_stride(segs);
+    c->d_arena = arena; c->d_seg_count = seg_count;
+    float* p = arena;
     auto take = [&]() { float* r = p; p += stride; return r; };
     for (int k = 0; k < 2; k++) {
         c->q[k].ox = take(); c->q[k].oy = take(); c->q[k].oz = take();
@@ -169,6 +173,16 @@ int alloc_path_buffers(rt_ctx* c, u32 segs) {
     c->gq.kx = take(); c->gq.ky = take(); c->gq.kz = take(); c->gq.ti = (int*) take();
     c->d_stack_spill = (int*) p; p += 48 * stride;
     c->n_paths = (u32) stride; c->n_segments_cap = segs;
+}
+
+// allocates the current set of path buffers for `segs` segments of 1024 queue slots
+int alloc_path_buffers(rt_ctx* c, u32 segs) {
+    u32* seg_count = nullptr; float* arena = nullptr;
+    RT_HIP(hipMalloc(&seg_count, sizeof(u32) * seg_count_words(segs)));
+    c->d_seg_count = seg_count; // owned from here on (freed with the context even if the next allocation fails)
+    RT_HIP(hipMemset(seg_count, 0, sizeof(u32) * seg_count_words(segs)));
+    RT_HIP(hipMalloc(&arena, path_stride(segs) * 4 * PATH_ARRAYS));
+    carve_path_buffers(c, arena, seg_count, segs);
     return RT_OK;
 }
 
@@ -177,7 +191,7 @@ int ensure_path_buffers(rt_ctx* c) {
     u32 tiles = ((c->width + 31) / 32) * ((c->height + 31) / 32);
     u32 segs = std::max(tiles, (c->n_points + 1023) / 1024);
     if (segs == 0) segs = 1;
-    if (segs * 1024 <= c->n_paths) return RT_OK;
+    if ((uint64_t) segs * 1024 <= c->n_paths) return RT_OK;
     dev_free(c->d_arena); dev_free(c->d_seg_count);
     dev_free(c->alt.d_arena); dev_free(c->alt.d_seg_count); // lane 1's set is allocated again, at the new size, when a dispatch first needs it
     memset(&c->alt, 0, sizeof c->alt);
@@ -438,6 +452,37 @@ extern "C" {
 const char* rt_last_error(void) { return g_error; }
 int rt_abi_version(void) { return RT_ABI_VERSION; }
 
+// ---- rt_dispatch_rays_static: the same frame with every scratch buffer in a static device array --------------------
+// No counterpart in the reference.  For callers that cannot allocate (HIP graph capture, serving loops, harnesses that
+// forbid hipMalloc): rt_dispatch_rays keeps its ray queues, hit records, path state, segment counters and traversal
+// stack overflow in buffers that it (re)allocates on demand; here they live in `scratch` below, which every context on
+// a GPU shares.  Host code never uses the array's name as an address: rt_create resolves it per device
+// (hipGetSymbolAddress) and everything goes through that pointer.
+static constexpr u32 RT_STATIC_MAX_SEGMENTS = 64;  // 65,536 queue slots: frames up to 64 tiles of 32x32 pixels (e.g. 256x256) and 65,536 sample points
+static constexpr size_t RT_STATIC_SEG_BYTES = 4096; // seg_count_words(64) * 4 = 1,028 bytes, padded: the arena behind it stays 256-byte aligned
+static constexpr size_t RT_STATIC_SCRATCH_BYTES = RT_STATIC_SEG_BYTES + (size_t) RT_STATIC_MAX_SEGMENTS * 1024 * 4 * PATH_ARRAYS; // 27,529,216
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int RT_MAX_DEVICES = 64;
+void* g_scratch_ptr[RT_MAX_DEVICES]; // device address of `scratch` on each GPU this process has created a context on
+std::mutex g_scratch_mutex;
+
+// with device `device` current: resolves this GPU's copy of `scratch` once
+int resolve_static_scratch(int device, void** out) {
+    if (device < 0 || device >= RT_MAX_DEVICES) { set_error("static scratch: device %d out of range", device); return RT_ERR_INVALID; }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) { set_error("static scratch: hipGetSymbolAddress returned a null address"); return RT_ERR_DEVICE; }
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+} // namespace
+
 namespace {
 int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_BVH_BUILDER")) c->bvh_builder = atoi(v);
@@ -457,7 +502,7 @@ int create_context(rt_ctx* c) {
     RT_HIP(hipMalloc(&c->d_stats, sizeof(DeviceStats)));
     RT_HIP(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
     for (int k = 0; k < 2; k++) RT_HIP(hipEventCreate(&c->build_ev[k]));
-    return RT_OK;
+    return resolve_static_scratch(c->device, &c->d_static_scratch); // rt_dispatch_rays_static
 }
 } // namespace
 
@@ -909,13 +954,50 @@ int rt_set_tile_split(rt_ctx* c, uint32_t rank, uint32_t world) {
     return RT_OK;
 }
 
-int rt_dispatch_rays(rt_ctx* c) {
+namespace {
+int validate_dispatch(rt_ctx* c) {
     if (!c) return RT_ERR_INVALID;
     if (c->width == 0 || c->n_instances == 0) { set_error("rt_dispatch_rays: needs rt_update_resolution and rt_build_tlas first"); return RT_ERR_STATE; }
     if (c->g.samples_per_pixel == 0 || c->g.bounces_per_sample > 64) { set_error("rt_dispatch_rays: samples_per_pixel must be >= 1 and bounces <= 64"); return RT_ERR_INVALID; }
     if (c->g.translucent_bssrdf_scale != 0.0f && c->n_points > 0 && !c->d_table[c->profile]) {
         set_error("rt_dispatch_rays: tabulated BSSRDF selected but profile %d was never loaded", c->profile); return RT_ERR_STATE;
     }
+    return RT_OK;
+}
+
+// one frame on c->stream with the context's current set of path buffers, nothing else in flight (the order of
+// raytracing.cpp:652-747)
+int dispatch_serial(rt_ctx* c) {
+    const bool collect = (c->flags & RT_FLAG_COLLECT_SAMPLES) && c->n_points > 0;
+    int rc = RT_OK;
+    if (c->n_points && c->sp_read_version[0] != c->sp_version) { // the last pipelined frame that collected samples ran on lane 1
+        RT_HIP(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream));
+        c->sp_read_version[0] = c->sp_version;
+    }
+    auto refresh_hg = [&]() -> int { // node sums of the payloads the camera pass is about to read
+        if (!(c->hg_enabled && c->hg_built)) return RT_OK;
+        PassArgs a; fill_pass_args(c, a, false);
+        return launch_hg_sums(c->stream, a, (u32) c->slices.size());
+    };
+    if (collect) { rc = run_pass(c, true); if (rc) return rc; }                       // raytracing.cpp:677-687
+    if (c->flags & RT_FLAG_DOUBLE_DISPATCH) { rc = refresh_hg(); if (rc) return rc; }
+    if (c->flags & RT_FLAG_DOUBLE_DISPATCH) { rc = run_pass(c, false); if (rc) return rc; } // :688-695
+    if (collect) {
+        RT_HIP(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream)); // :723-728
+        c->sp_read_version[0] = ++c->sp_version;
+    }
+    rc = refresh_hg(); if (rc) return rc;
+    rc = run_pass(c, false); if (rc) return rc;                                       // :734-741
+    c->render_target_stale = false;
+    c->dispatch_index++;
+    c->g.accumulator_count += 1;                                                      // :744
+    c->g.translucent_accumulator_count += (c->flags & RT_FLAG_COLLECT_SAMPLES) ? 1u : 0u; // :745
+    return RT_OK;
+}
+} // namespace
+
+int rt_dispatch_rays(rt_ctx* c) {
+    { int vrc = validate_dispatch(c); if (vrc) return vrc; }
     RT_HIP(hipSetDevice(c->device));
     bool collect = (c->flags & RT_FLAG_COLLECT_SAMPLES) && c->n_points > 0;
     const bool gather = c->n_points > 0 && (c->flags & RT_FLAG_ENABLE_SSS) && c->g.translucent_bssrdf_fudge != 0.0f;
@@ -961,29 +1043,43 @@ int rt_dispatch_rays(rt_ctx* c) {
     }
     int rc = quiesce(c); if (rc) return rc;
     rc = ensure_path_buffers(c); if (rc) return rc;
-    if (c->n_points && c->sp_read_version[0] != c->sp_version) { // the last pipelined frame that collected samples ran on lane 1
-        RT_HIP(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream));
-        c->sp_read_version[0] = c->sp_version;
+    return dispatch_serial(c);
+}
+
+int rt_dispatch_rays_static(rt_ctx* c) {
+    { int vrc = validate_dispatch(c); if (vrc) return vrc; }
+    if (!c->d_static_scratch) { set_error("rt_dispatch_rays_static: the static scratch was not resolved at rt_create"); return RT_ERR_STATE; }
+    if (c->flags & (RT_FLAG_CAPTURE_HITS | RT_FLAG_TIME_KERNELS)) {
+        set_error("rt_dispatch_rays_static: RT_FLAG_CAPTURE_HITS and RT_FLAG_TIME_KERNELS allocate (capture buffer, events); use rt_dispatch_rays");
+        return RT_ERR_UNSUPPORTED;
     }
-    auto refresh_hg = [&]() -> int { // node sums of the payloads the camera pass is about to read
-        if (!(c->hg_enabled && c->hg_built)) return RT_OK;
-        PassArgs a; fill_pass_args(c, a, false);
-        return launch_hg_sums(c->stream, a, (u32) c->slices.size());
+    const u32 tiles = ((c->width + 31) / 32) * ((c->height + 31) / 32);
+    const u32 segs = std::max(std::max(tiles, (c->n_points + 1023) / 1024), 1u);
+    if (segs > RT_STATIC_MAX_SEGMENTS) {
+        set_error("rt_dispatch_rays_static: %ux%u pixels / %u sample points need %u queue segments, the static scratch holds %u "
+                  "(at most 64 tiles of 32x32 pixels and 65,536 sample points); use rt_dispatch_rays", c->width, c->height, c->n_points, segs, RT_STATIC_MAX_SEGMENTS);
+        return RT_ERR_LIMIT;
+    }
+    RT_HIP(hipSetDevice(c->device));
+    int rc = quiesce(c); if (rc) return rc; // a no-op unless rt_dispatch_rays left frames in flight on the context's own streams
+    // the context's own buffers step aside for this call
+    rt_ctx::PathBuffers own; memset(&own, 0, sizeof own);
+    const u32 own_paths = c->n_paths, own_cap = c->n_segments_cap;
+    auto exchange = [&]() {
+        std::swap(c->d_arena, own.d_arena); std::swap(c->d_seg_count, own.d_seg_count); std::swap(c->hits, own.hits); std::swap(c->ps, own.ps);
+        std::swap(c->gq, own.gq); std::swap(c->d_stack_spill, own.d_stack_spill);
+        for (int k = 0; k < 2; k++) { std::swap(c->q[k], own.q[k]); std::swap(c->st[k], own.st[k]); }
     };
-    if (collect) { rc = run_pass(c, true); if (rc) return rc; }                       // raytracing.cpp:677-687
-    if (c->flags & RT_FLAG_DOUBLE_DISPATCH) { rc = refresh_hg(); if (rc) return rc; }
-    if (c->flags & RT_FLAG_DOUBLE_DISPATCH) { rc = run_pass(c, false); if (rc) return rc; } // :688-695
-    if (collect) {
-        RT_HIP(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream)); // :723-728
-        c->sp_read_version[0] = ++c->sp_version;
-    }
-    rc = refresh_hg(); if (rc) return rc;
-    rc = run_pass(c, false); if (rc) return rc;                                       // :734-741
-    c->render_target_stale = false;
-    c->dispatch_index++;
-    c->g.accumulator_count += 1;                                                      // :744
-    c->g.translucent_accumulator_count += (c->flags & RT_FLAG_COLLECT_SAMPLES) ? 1u : 0u; // :745
-    return RT_OK;
+    exchange();
+    unsigned char* base = (unsigned char*) c->d_static_scratch;
+    carve_path_buffers(c, (float*) (base + RT_STATIC_SEG_BYTES), (u32*) base, RT_STATIC_MAX_SEGMENTS);
+    // the array keeps the last call's contents: the segment fills start at zero like freshly allocated ones
+    hipError_t e = hipMemsetAsync(base, 0, RT_STATIC_SEG_BYTES, c->stream);
+    if (e != hipSuccess) { set_error("rt_dispatch_rays_static: hipMemsetAsync failed: %s", hipGetErrorString(e)); rc = RT_ERR_DEVICE; }
+    if (rc == RT_OK) rc = dispatch_serial(c);
+    exchange();
+    c->n_paths = own_paths; c->n_segments_cap = own_cap;
+    return rc;
 }
 
 int rt_sync(rt_ctx* c) {

@@ -1,0 +1,69 @@
+"""rt_dispatch_rays_static (include/rt_abi.h): the frame of rt_dispatch_rays with every scratch buffer in a static
+device array, for callers that cannot allocate.  Checked through the C-ABI against rt_dispatch_rays itself, bit for
+bit, on two calls in a row on one context, the second at a smaller resolution (the array keeps the first call's
+contents), for a plain camera scene and for one with the sample-point pass and the BSSRDF gather; and the limits."""
+import numpy as np
+import pytest
+
+from raytracer_amd import scenes, distributed
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(rt, scene, static, frames):
+    for f in range(frames):
+        g = scene.globals.copy()
+        cur = rt.get_globals()
+        g.frame_rng = distributed.frame_seed(scene.globals.frame_rng, f)
+        g.accumulator_count = cur.accumulator_count
+        g.translucent_accumulator_count = cur.translucent_accumulator_count
+        rt.set_globals(g)
+        if static:
+            rt.dispatch_rays_static()
+        else:
+            rt.dispatch_rays()
+    pts = [rt.read_sample_points(i)[0] for i in range(rt.translucent_instance_count())]
+    return rt.read_accumulator(), rt.read_render_target(), pts
+
+
+@pytest.mark.parametrize("make", [lambda w, h: scenes.bunny(w, h, spp=2, bounces=3),
+                                  lambda w, h: scenes.cornell_bunny(w, h, spp=1, bounces=3, sample_radius=0.05)],
+                         ids=["bunny", "cornell_bunny_bssrdf"])
+def test_static_dispatch_equals_dispatch_twice_in_a_row(make, monkeypatch):
+    from raytracer_amd import api
+    monkeypatch.setenv("RT_FRAMES_IN_FLIGHT", "1")   # the reference run: one frame at a time, like the static entry point
+    ref, sta = api.Raytracer(0), api.Raytracer(0)
+    try:
+        for (w, h) in ((256, 250), (101, 67)):       # 64 tiles (the limit), then 12 partly filled ones
+            scene = make(w, h)
+            n_ref, n_sta = scene.setup(ref), scene.setup(sta)
+            assert n_ref == n_sta
+            a = _render(ref, scene, False, 3)
+            b = _render(sta, scene, True, 3)
+            assert a[0].any()
+            assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), (w, h)
+            assert np.array_equal(a[1], b[1]), (w, h)
+            assert len(a[2]) == len(b[2]) and all(x.tobytes() == y.tobytes() for x, y in zip(a[2], b[2]))
+    finally:
+        ref.close(); sta.close()
+
+
+def test_static_dispatch_rejects_what_does_not_fit():
+    from raytracer_amd import api, _abi
+    rt = api.Raytracer(0)
+    try:
+        scene = scenes.bunny(264, 256, spp=1, bounces=1)   # 9 x 8 = 72 tiles > 64
+        scene.setup(rt)
+        with pytest.raises(RuntimeError, match="static scratch holds 64"):
+            rt.dispatch_rays_static()
+        rt.dispatch_rays()                                  # the allocating entry point still takes it
+        scene = scenes.bunny(64, 64, spp=1, bounces=1)
+        scene.setup(rt)
+        rt.set_flags(scene.flags | _abi.RT_FLAG_CAPTURE_HITS)
+        with pytest.raises(RuntimeError, match="allocate"):
+            rt.dispatch_rays_static()
+        rt.set_flags(scene.flags)
+        rt.dispatch_rays_static()
+        assert rt.read_accumulator().any()
+    finally:
+        rt.close()
