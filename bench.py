@@ -6,14 +6,22 @@ bounces_per_sample = 1 ("primary + shadow" rays).  One step = one 
 (raytracing.cpp:652-747) with the frame_rng chain of main.cpp:443-454 advancing, so every step traces a different
 sample set into the progressive accumulator.  Inputs (scene, BVH, path buffers) are resident in HBM before timing.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): sample-set split.  Rank r renders
-frames r, r+N, ... of the chain into a private accumulator (full scene replica per GPU, no data-path collective);
-after the K steps one RCCL reduce(sum) of the RGBA32F accumulator to rank 0 closes the timed region.  Per-GPU work is
-fixed => "scaling": "weak".
+N > 1 (launched by torch.distributed.run, one rank per GPU), full scene replica per GPU, two partitions:
+  --split sample (default; C5)  rank r renders frames r, r+N, ... of the chain into a private accumulator; per-GPU work
+                                is fixed => "scaling": "weak".
+  --split tile   (default for --workload c4)  every rank renders every frame, but only the 32x32 tiles t with
+                                t % N == r (rt_set_tile_split); total work is fixed => "scaling": "strong".
+Either way no collective runs during the K steps; one RCCL reduce(sum) of the RGBA32F accumulators to rank 0 closes
+the timed region (its duration is reported separately as `reduce_ms`).
 
 The JSON line also carries
-  roofline:     the dominant kernel (k_traverse): algorithmic bytes/ray x rays per launch / mean launch time (HIP events
-                on the library's stream) against the 8 TB/s HBM peak;
+  roofline:     the dominant kernel (k_traverse).  What bounds it is vector-instruction issue, not HBM (the scenes are
+                cache resident): `achieved` = wave64 vector instructions per launch (SQ_INSTS_VALU of the committed PMC
+                pass of this command, profiles/pmc_traffic.json) / mean launch time (live HIP events on the library's
+                streams); `peak` = 1,024 SIMDs x 2.4 GHz / the cycles a SIMD needs per instruction at best
+                (tools/valu_issue_bench.hip -> profiles/r02_valu_issue.txt: v_fma_f32 / v_mul_f32 with 8 waves per SIMD),
+                so frac <= 1 by construction.  `traffic` / `traffic_frac` are the HBM bytes per launch of the same PMC
+                passes against 8 TB/s; `model` keeps SURVEY.md 8(d)'s bytes-per-ray figure (not an HBM ceiling).
   cpu_baseline: the CPU oracle (oracle/, test infrastructure) timed on this host on a bounded sample of the same
                 workload; it also supplies the per-ray node/triangle/instance counts of the bytes-per-ray model.
 """
@@ -27,6 +35,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+SIMDS = 1024           # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4        # MI355X_MICROARCH.md: max clock (the chip holds 2.1-2.4 GHz under these loads: frac is conservative)
+
+
+def valu_issue_cycles():
+    """Cycles one SIMD needs per wave64 vector instruction, measured by tools/valu_issue_bench.hip on MI355X and committed
+    as profiles/r02_valu_issue.txt (column `wall` at 8 waves per SIMD): `best` = the cheapest class (v_mul_f32 /
+    v_fma_f32), `mix` = the select / fma_mix / max / fma blend of k_traverse's node step."""
+    best, mix = None, None
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r02_valu_issue.txt")):
+            f = line.split()
+            if len(f) == 6 and f[1] == "8":
+                if f[0] in ("v_fma_f32", "v_mul_f32"):
+                    best = float(f[4]) if best is None else min(best, float(f[4]))
+                if f[0].startswith("mix("):
+                    mix = float(f[4])
+    except (OSError, ValueError):
+        pass
+    return best, mix
 
 
 class _DevBuf(object):
@@ -98,6 +126,9 @@ def main():
     ap.add_argument("--no-alone", action="store_true",
                     help="skip the one-frame-at-a-time leg (roofline.one_frame_in_flight), e.g. under rocprofv3, so that the "
                          "kernel statistics hold only launches of the timed regime")
+    ap.add_argument("--split", choices=["sample", "tile"], default=None,
+                    help="N > 1: sample-set split (frames r, r+N, ... per rank; default) or tile split (32x32 tiles t % N == r "
+                         "of every frame; default for --workload c4)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a one-GPU box: every rank uses GPU 0 and the collectives go through gloo (checks the "
                          "multi-rank code path; the numbers mean nothing)")
@@ -105,6 +136,8 @@ def main():
     ap.add_argument("--hg", type=float, default=None, metavar="STERADIANS",
                     help="hierarchical BSSRDF gather with this solid-angle limit (rt_set_gather_mode; not reference behaviour)")
     args = ap.parse_args()
+    if args.split is None:
+        args.split = "tile" if args.workload == "c4" else "sample"
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -123,24 +156,29 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from raytracer_amd import api, host, _abi
+    from raytracer_amd import api, host, _abi, distributed
     scene, label = build_scene(args.workload, args)
     if args.hg is not None:
         scene.gather_mode = (True, args.hg)
         label += " [hierarchical gather, limit %g sr]" % args.hg
     rt = api.Raytracer(local_rank)
     points = scene.setup(rt)
+    tile = world > 1 and args.split == "tile"
+    if tile:
+        rt.set_tile_split(rank, world)
+    elif world > 1 and points:
+        distributed.require_no_sample_points(rt)   # payloads accumulate frame by frame: such scenes shard by tiles
     acc_ptr, acc_bytes = rt.accumulator_device_ptr()
     acc = torch.as_tensor(_DevBuf(acc_ptr, acc_bytes // 4), device=torch.device("cuda", local_rank))
     del acc_ptr
 
-    from raytracer_amd import distributed
     chain = distributed.FrameChain(scene.globals.frame_rng)
     step_index = [0]
 
     def step(timed):
-        # sample-set split: this rank owns frames rank, rank + world, ... of the frame_rng chain
-        distributed.render_frame(rt, scene.globals, step_index[0] * world + rank, chain)
+        # sample-set split: this rank owns frames rank, rank + world, ... of the frame_rng chain;
+        # tile split: every rank renders every frame (its own tiles of it)
+        distributed.render_frame(rt, scene.globals, step_index[0] if tile else step_index[0] * world + rank, chain)
         step_index[0] += 1
 
     for _ in range(args.warmup):
@@ -173,6 +211,7 @@ def main():
     for _ in range(args.steps):
         step(True)
     rt.sync()
+    t_render = time.perf_counter()
     if dist is not None:
         if args.rehearse:
             dist.all_reduce(acc, op=dist.ReduceOp.SUM)  # gloo has no GPU reduce
@@ -180,17 +219,20 @@ def main():
             dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)   # RCCL over xGMI: combine the float accumulation buffers
     fence()
     dt = time.perf_counter() - t0
+    reduce_ms = (time.perf_counter() - t_render) * 1e3 if dist is not None else 0.0   # this rank's wait for the slowest rank included
 
     stats = rt.get_stats()
     rays = stats["rays_camera"] + stats["rays_probe"]
-    t_rays = torch.tensor([float(rays), dt], dtype=torch.float64, device="cuda")
+    # the tile split replicates the (small) sample-point pass on every rank: those rays are counted once
+    job_rays = stats["rays_camera"] + (stats["rays_probe"] if (not tile or rank == 0) else 0)
+    t_rays = torch.tensor([float(job_rays), dt], dtype=torch.float64, device="cuda")
     if dist is not None:
         tmax = t_rays.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t_rays, op=dist.ReduceOp.SUM)
         total_rays, dt_max = float(t_rays[0].item()), float(tmax[1].item())
     else:
-        total_rays, dt_max = float(rays), dt
+        total_rays, dt_max = float(job_rays), dt
 
     if rank == 0:
         # traversal counters of this GPU's own BVH (one extra untimed frame with the counting kernel variant)
@@ -234,7 +276,8 @@ def main():
         if model is None:
             model = gpu_counts
         # B_ray = 200 + 64 N_node + 48 N_tri + 64 N_inst; the traverse kernel's share of the 200 B of
-        # stream traffic is the 32 B ray it reads and the 20 B hit it writes.
+        # stream traffic is the 32 B ray it reads and the 20 B hit it writes.  Kept as `roofline.model`: these are bytes
+        # that L1 / L2 serve, not HBM bytes, so they are not a ceiling (round 1 reported 1.18 of the HBM peak with them).
         b_trav = 52.0 + 64.0 * model["n_node"] + 48.0 * model["n_tri"] + 64.0 * model["n_inst"]
         b_ray = 200.0 + 64.0 * model["n_node"] + 48.0 * model["n_tri"] + 64.0 * model["n_inst"]
         launches = max(stats["traverse_launches"], 1)
@@ -242,16 +285,45 @@ def main():
         mean_launch_ms = stats["traverse_ms"] / timed
         rays_per_launch = rays / launches
         rays_timed = rays * timed / launches  # frames are statistically alike: the timed launches carry their share of the rays
-        achieved = (b_trav * rays_per_launch) / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
-        # HBM bytes per k_traverse launch from the committed PMC passes of this same command (tools/pmc_passes.sh +
-        # tools/pmc_summary.py: FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as is); null for other workloads
-        traffic = None
-        if args.workload == "c2" and (args.width, args.height) == (1920, 1080):
+        model_gbs = (b_trav * rays_per_launch) / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
+        # queued (scattered / sample-point: incoherent) launches apart from the bounce-0 launches: north_star's
+        # ">= 1 Grays/s incoherent secondary rays" is read off `secondary_Mrays_s`
+        sec_launches = stats["traverse_launches"] - stats["primary_launches"]
+        sec_timed = stats["traverse_launches_timed"] - stats["primary_launches_timed"]
+        sec_ms = stats["traverse_ms"] - stats["primary_ms"]
+        sec_rays = rays - stats["rays_primary"]
+        secondary = primary = None
+        if sec_timed > 0 and sec_ms > 0 and sec_launches > 0:
+            secondary = (sec_rays * sec_timed / sec_launches) / (sec_ms * 1e-3) / 1e6
+        if stats["primary_launches_timed"] > 0 and stats["primary_ms"] > 0:
+            primary = (stats["rays_primary"] * stats["primary_launches_timed"] / stats["primary_launches"]) / (stats["primary_ms"] * 1e-3) / 1e6
+        # per-launch counters of k_traverse from the committed PMC passes of this same command (tools/pmc_passes.sh +
+        # tools/pmc_summary.py -> profiles/pmc_traffic.json; HBM bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB per the gfx950
+        # note of MI355X_MICROARCH.md); only for the workload they were taken on
+        pmc = None
+        if (args.width, args.height) == (1920, 1080) and world == 1:
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                traffic = pmc["c2"]["kernels"]["k_traverse"]["traffic_bytes_per_launch"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[args.workload]["kernels"]["k_traverse"]
             except (OSError, KeyError, ValueError):
-                traffic = None
+                pmc = None
+        cyc_best, cyc_mix = valu_issue_cycles()
+        traffic = insts = achieved = peak = frac = traffic_frac = mix_frac = valu_busy = None
+        if pmc is not None:
+            traffic = pmc.get("traffic_bytes_per_launch")
+            insts = pmc.get("SQ_INSTS_VALU")
+        if traffic is not None and mean_launch_ms > 0:
+            traffic_frac = traffic / (mean_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if insts is not None and cyc_best is not None and mean_launch_ms > 0:
+            achieved = insts / (mean_launch_ms * 1e-3) / 1e9            # G wave64 vector instructions per second
+            peak = SIMDS * CLOCK_GHZ / cyc_best
+            frac = achieved / peak
+            mix_frac = achieved * cyc_mix / (SIMDS * CLOCK_GHZ) if cyc_mix else None
+            assert frac <= 1.0, "roofline.frac %g > 1: the PMC pass in profiles/ does not belong to this build" % frac
+            if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
+                # the hardware's own tally, from the PMC run itself: quad-cycles in which a SIMD executes a vector
+                # instruction over the SIMD quad-cycles of the launch (GRBM_GUI_ACTIVE sums the 8 XCDs)
+                valu_busy = 4.0 * pmc["SQ_ACTIVE_INST_VALU"] / (SIMDS * pmc["GRBM_GUI_ACTIVE"] / 8.0)
+        split_label = ("tile split x%d" if tile else "sample-set split x%d") % world
         out = {
             # BASELINE.json's metric; `value` is the whole job: per GPU at N = 1, the sum over the N GPUs otherwise
             "metric": ("Mrays/s per GPU (primary+secondary) at 1080p" if world == 1 else "Mrays/s over %d GPUs (primary+secondary) at 1080p" % world)
@@ -260,34 +332,54 @@ def main():
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if tile else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": args.width, "height": args.height, "triangles": scene.triangle_count(),
                        "sample_points": points, "rays_per_step_per_gpu": rays / args.steps,
-                       "parallelism": "sample-set split x%d + RCCL reduce" % world if world > 1 else "single GPU",
+                       "parallelism": split_label + " + RCCL reduce" if world > 1 else "single GPU",
                        # consecutive steps overlap pairwise on the GPU (the library's default, RT_FRAMES_IN_FLIGHT)
                        "frames_in_flight": out_frames_in_flight(args)},
-            "roofline": {"bound": "hbm", "kernel": "k_traverse", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": b_trav * rays_per_launch,
-                         "bytes_per_ray_traverse": b_trav, "bytes_per_ray_pipeline": b_ray,
-                         # what this implementation's records actually are (32-byte packed nodes, 48-byte triangles,
-                         # 96-byte instance records) times its own trees' counts; the figure above is SURVEY 8(d)'s model
-                         "bytes_per_ray_traverse_this_layout": 52.0 + 32.0 * gpu_counts["n_node"] + 48.0 * gpu_counts["n_tri"] + 96.0 * gpu_counts["n_inst"],
+            "primary_Mrays_s": primary,        # bounce-0 launches alone (coherent), from their launch durations
+            "secondary_Mrays_s": secondary,    # queued launches alone (scattered / sample-point rays: incoherent)
+            "reduce_ms": reduce_ms if world > 1 else None,   # the one collective, inside the timed region (rank 0's view)
+            "roofline": {"bound": "valu_issue", "kernel": "k_traverse", "achieved": achieved, "peak": peak, "unit": "Ginst/s",
+                         "frac": frac, "traffic": traffic, "traffic_frac": traffic_frac,
+                         "valu_insts_per_launch": insts, "cycles_per_inst_best": cyc_best, "cycles_per_inst_node_step_mix": cyc_mix,
+                         # the same instruction rate priced at the measured cost of the node step's instruction blend
+                         # (selects, v_fma_mix, min / max run at half the fma rate on gfx950): how full the issue slots are
+                         "frac_at_mix_cost": mix_frac, "valu_busy_pmc": valu_busy,
                          "mean_launch_ms": mean_launch_ms, "rays_per_launch": rays_per_launch,
                          "traverse_Mrays_s": rays_timed / (stats["traverse_ms"] * 1e-3) / 1e6 if stats["traverse_ms"] > 0 else None,
                          "launches_timed": stats["traverse_launches_timed"], "launches": stats["traverse_launches"],
-                         "model_counts": model, "gpu_bvh_counts": gpu_counts,
+                         # SURVEY 8(d)'s algorithmic byte model (64-byte nodes, every byte priced as if it came from HBM)
+                         "model": {"bytes_per_ray_traverse": b_trav, "bytes_per_ray_pipeline": b_ray,
+                                   "algorithmic_bytes_per_launch": b_trav * rays_per_launch, "GBs": model_gbs,
+                                   "frac_of_hbm_peak": model_gbs / HBM_PEAK_GBS,
+                                   # what this implementation's records actually are (32-byte packed nodes, 48-byte triangles,
+                                   # 96-byte instance records) times its own trees' counts
+                                   "bytes_per_ray_traverse_this_layout": 52.0 + 32.0 * gpu_counts["n_node"] + 48.0 * gpu_counts["n_tri"] + 96.0 * gpu_counts["n_inst"],
+                                   "model_counts": model, "gpu_bvh_counts": gpu_counts},
                          # launches of the timed region share the GPU with the other frame in flight; this is the same
                          # kernel with the GPU to itself (frames one at a time), and what the job then runs at
-                         "one_frame_in_flight": None if alone is None else dict(alone, achieved=(b_trav * rays_per_launch) / (alone["mean_launch_ms"] * 1e-3) / 1e9,
-                                                                                frac=(b_trav * rays_per_launch) / (alone["mean_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS)},
+                         "one_frame_in_flight": None if alone is None else dict(
+                             alone, achieved=None if insts is None else insts / (alone["mean_launch_ms"] * 1e-3) / 1e9,
+                             frac=None if (insts is None or peak is None) else insts / (alone["mean_launch_ms"] * 1e-3) / 1e9 / peak)},
             "cpu_baseline": cpu_line,
         }
         # acceleration-structure builds are outside the timed loop: reported separately
         out["build"] = {"last_blas_ms": stats["blas_build_ms"], "blas_triangles_total": stats["blas_triangles"],
                         "tlas_ms": stats["tlas_build_ms"], "tlas_instances": stats["tlas_instances"],
                         "tlas_Minstances_per_s": stats["tlas_instances"] / (stats["tlas_build_ms"] * 1e-3) / 1e6 if stats["tlas_build_ms"] > 0 else None}
+        if points:
+            # blue-noise sample-point generation (rt_generate_translucent_samples blocks: host wall time), at the scene's
+            # radius and at a finer one (the reference's slow, unprofiled step, todo.txt:3-4)
+            out["build"]["bluenoise_ms"] = stats["bluenoise_ms"]
+            out["build"]["bluenoise_points"] = stats["bluenoise_points"]
+            out["build"]["bluenoise_radius"] = scene.sample_radius
+            if world == 1:
+                n_fine = rt.generate_translucent_samples(0.01, scene.rng_seed, scene.phase_seed)
+                fine = rt.get_stats()
+                out["build"]["bluenoise_fine"] = {"radius": 0.01, "ms": fine["bluenoise_ms"], "points": n_fine}
         if stats["gather_launches"] and stats["gather_ms"] > 0:
             # second hot loop: (hit, sample point) pairs of translucent_chit; 24 B per pair from LDS
             gtimed = max(stats["gather_launches_timed"], 1)

@@ -136,6 +136,12 @@ typedef struct RtStats {
     double   gather_ms;            /* their summed duration with RT_FLAG_TIME_KERNELS (HIP events on the context's stream) */
     uint64_t traverse_launches_timed; /* launches that traverse_ms covers (all of them, or every 8th dispatch with RT_FLAG_TIME_SAMPLED) */
     uint64_t gather_launches_timed;   /* launches that gather_ms covers */
+    uint64_t primary_launches;        /* the bounce-0 launches among traverse_launches: coherent rays derived from pixels; the rest */
+    uint64_t primary_launches_timed;  /* are queued launches of scattered ("secondary", incoherent) or sample-point rays          */
+    double   primary_ms;              /* the part of traverse_ms spent in the timed bounce-0 launches                             */
+    uint64_t rays_primary;            /* the part of rays_camera traced by bounce-0 launches                                      */
+    double   bluenoise_ms;            /* host wall time of the last rt_generate_translucent_samples (it blocks), all instances    */
+    uint64_t bluenoise_points;        /* sample points it produced                                                                */
 } RtStats;
 
 /* rt_set_flags bits */

@@ -65,7 +65,9 @@ class RtStats(C.Structure):
                 ("tlas_build_ms", C.c_double), ("blas_triangles", C.c_uint64), ("tlas_instances", C.c_uint64),
                 ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64), ("wave_instance_steps", C.c_uint64),
                 ("max_ray_steps", C.c_uint64), ("gather_launches", C.c_uint64), ("gather_ms", C.c_double),
-                ("traverse_launches_timed", C.c_uint64), ("gather_launches_timed", C.c_uint64)]
+                ("traverse_launches_timed", C.c_uint64), ("gather_launches_timed", C.c_uint64),
+                ("primary_launches", C.c_uint64), ("primary_launches_timed", C.c_uint64), ("primary_ms", C.c_double),
+                ("rays_primary", C.c_uint64), ("bluenoise_ms", C.c_double), ("bluenoise_points", C.c_uint64)]
 
 
 def load_library(path):

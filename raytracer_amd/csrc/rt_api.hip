@@ -4,6 +4,7 @@
 #include "rt_internal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -110,11 +111,13 @@ struct rt_ctx {
     // BSSRDF tables
     float* d_table[2] = { nullptr, nullptr }; int table_texels[2] = { 0, 0 }; int profile = 0;
     // stats
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, timed_gather; double traverse_ms = 0, gather_ms = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, timed_primary, timed_gather; double traverse_ms = 0, traverse_primary_ms = 0, gather_ms = 0;
     uint64_t traverse_launches = 0, gather_launches = 0, primary_rays = 0, traverse_launches_timed = 0, gather_launches_timed = 0;
+    uint64_t primary_launches = 0, primary_launches_timed = 0; // the bounce-0 launches among the traverse launches (coherent rays derived from pixels)
     uint64_t dispatch_index = 0; // rt_dispatch_rays calls so far (RT_FLAG_TIME_SAMPLED times every 8th)
     double blas_build_ms = 0, tlas_build_ms = 0; uint64_t blas_triangles = 0;
     void* d_static_scratch = nullptr; // this GPU's copy of the static scratch array of rt_dispatch_rays_static (resolved at rt_create)
+    double bluenoise_ms = 0; uint64_t bluenoise_points = 0; // wall time and result of the last rt_generate_translucent_samples
     hipEvent_t build_ev[2] = { nullptr, nullptr }; // bracket the builds of rt_build_blas / rt_build_tlas (created once: no error path can leak them)
     rt_ctx() { memset(&g, 0, sizeof g); memset(q, 0, sizeof q); memset(&hits, 0, sizeof hits); memset(&ps, 0, sizeof ps); memset(st, 0, sizeof st); memset(&gq, 0, sizeof gq); memset(&alt, 0, sizeof alt); }
 };
@@ -304,9 +307,9 @@ int timed_traverse(rt_ctx* c, const PassArgs& a, u32 inq, bool primary, u32 samp
         c->traverse_launches_timed++;
     }
     int rc = launch_traverse(c->stream, a, inq, (c->flags & RT_FLAG_COUNT_TRAVERSAL) != 0, primary, sample_index);
-    if (timing) { RT_HIP(hipEventRecord(e1, c->stream)); c->timed.emplace_back(e0, e1); }
+    if (timing) { RT_HIP(hipEventRecord(e1, c->stream)); (primary ? c->timed_primary : c->timed).emplace_back(e0, e1); if (primary) c->primary_launches_timed++; }
     c->traverse_launches++;
-    if (primary) c->primary_rays += local_pixel_count(a); // bounce-0 rays are not queued, so the device does not count them
+    if (primary) { c->primary_launches++; c->primary_rays += local_pixel_count(a); } // bounce-0 rays are not queued, so the device does not count them
     return rc;
 }
 
@@ -339,6 +342,13 @@ int drain_timers(rt_ctx* c) {
         (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second);
     }
     c->timed.clear();
+    for (auto& pr : c->timed_primary) {
+        RT_HIP(hipEventSynchronize(pr.second));
+        float ms = 0; RT_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        c->traverse_ms += ms; c->traverse_primary_ms += ms;
+        (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second);
+    }
+    c->timed_primary.clear();
     return RT_OK;
 }
 
@@ -743,6 +753,7 @@ int rt_generate_translucent_samples(rt_ctx* c, float radius, uint32_t rng_seed, 
     if (c->g.translucent_instance_stride == 0) return RT_OK; // raytracing.cpp:554
     RT_HIP(hipSetDevice(c->device));
     RT_HIP(hipStreamSynchronize(c->stream));
+    const auto wall0 = std::chrono::steady_clock::now(); // the call blocks: its wall time is the cost of the blue-noise set-up (todo.txt:4)
     free_sample_points(c);
     u32 stride = c->g.translucent_instance_stride;
     c->slot_count = (u32) c->translucent_mean_area.size() * stride;
@@ -835,6 +846,8 @@ int rt_generate_translucent_samples(rt_ctx* c, float radius, uint32_t rng_seed, 
     for (auto p : d_normals) if (p) (void) hipFree(p);
     if (status != RT_OK) { free_sample_points(c); return status; }
     *total = n_total;
+    c->bluenoise_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    c->bluenoise_points = n_total;
     int hrc = hg_build_all(c); if (hrc) return hrc;
     return ensure_path_buffers(c);
 }
@@ -1146,6 +1159,9 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
     out->traverse_launches = c->traverse_launches; out->traverse_ms = c->traverse_ms;
     out->gather_launches = c->gather_launches; out->gather_ms = c->gather_ms;
     out->traverse_launches_timed = c->traverse_launches_timed; out->gather_launches_timed = c->gather_launches_timed;
+    out->primary_launches = c->primary_launches; out->primary_launches_timed = c->primary_launches_timed;
+    out->primary_ms = c->traverse_primary_ms; out->rays_primary = c->primary_rays;
+    out->bluenoise_ms = c->bluenoise_ms; out->bluenoise_points = c->bluenoise_points;
     out->blas_build_ms = c->blas_build_ms; out->tlas_build_ms = c->tlas_build_ms;
     out->blas_triangles = c->blas_triangles; out->tlas_instances = c->n_instances;
     return RT_OK;
@@ -1157,6 +1173,7 @@ int rt_reset_stats(rt_ctx* c) {
     int rc = drain_timers(c); if (rc) return rc;
     RT_HIP(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
     c->traverse_ms = 0; c->traverse_launches = 0; c->primary_rays = 0; c->gather_ms = 0; c->gather_launches = 0;
+    c->traverse_primary_ms = 0; c->primary_launches = 0; c->primary_launches_timed = 0;
     c->traverse_launches_timed = 0; c->gather_launches_timed = 0;
     return RT_OK;
 }
