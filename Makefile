@@ -11,7 +11,7 @@ HIP_SRCS := $(CSRC)/rt_api.hip $(CSRC)/rt_kernels.hip $(CSRC)/rt_bvh.hip $(CSRC)
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
 HIP_HDRS := $(wildcard $(CSRC)/*.h) include/rt_abi.h
 
-all: raytracer_amd/librt_mi355x.so raytracer_amd/librt_host.so oracle/liboracle.so raytracer_amd/rt_render
+all: raytracer_amd/librt_mi355x.so raytracer_amd/librt_host.so oracle/liboracle.so raytracer_amd/rt_render tools/valu_issue_bench
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -19,12 +19,16 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 raytracer_amd/librt_mi355x.so: $(HIP_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS)
 
-raytracer_amd/librt_host.so: raytracer_amd/host/rt_host.cpp include/rt_host.h include/rt_abi.h
-	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -shared -o $@ raytracer_amd/host/rt_host.cpp
+raytracer_amd/librt_host.so: raytracer_amd/host/rt_host.cpp raytracer_amd/host/rt_scene.cpp include/rt_host.h include/rt_abi.h
+	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -shared -o $@ raytracer_amd/host/rt_host.cpp raytracer_amd/host/rt_scene.cpp
 
 # headless frame loop (main.cpp replacement) on top of the two libraries
 raytracer_amd/rt_render: raytracer_amd/host/rt_render.cpp raytracer_amd/host/raytracing.hpp raytracer_amd/librt_mi355x.so raytracer_amd/librt_host.so
 	$(CXX) -O2 -std=c++17 -Wall -o $@ raytracer_amd/host/rt_render.cpp -Lraytracer_amd -lrt_mi355x -lrt_host '-Wl,-rpath,$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+
+# microbenchmark behind bench.py's roofline peak (profiles/r02_valu_issue.txt)
+tools/valu_issue_bench: tools/valu_issue_bench.hip
+	$(HIPCC) --offload-arch=gfx950 -O2 -o $@ $<
 
 oracle/liboracle.so: oracle/rt_oracle.cpp include/rt_abi.h
 	$(MAKE) -C oracle

@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a one-GPU box: every rank uses GPU 0 and the collectives go through gloo (checks the "
                          "multi-rank code path; the numbers mean nothing)")
+    ap.add_argument("--dump-accumulator", default=None, metavar="FILE.npy",
+                    help="rank 0 saves the float accumulator as it stands when the timed region ends (after the reduce): "
+                         "lets a test compare the multi-rank image with the one-process image")
     ap.add_argument("--sample-radius", type=float, default=0.025, help="blue-noise rejection radius of c4 (main.cpp:50)")
     ap.add_argument("--hg", type=float, default=None, metavar="STERADIANS",
                     help="hierarchical BSSRDF gather with this solid-angle limit (rt_set_gather_mode; not reference behaviour)")
@@ -220,6 +223,9 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     reduce_ms = (time.perf_counter() - t_render) * 1e3 if dist is not None else 0.0   # this rank's wait for the slowest rank included
+    if args.dump_accumulator and rank == 0:
+        import numpy as np
+        np.save(args.dump_accumulator, acc.cpu().numpy().reshape(args.height, args.width, 4))
 
     stats = rt.get_stats()
     rays = stats["rays_camera"] + stats["rays_probe"]

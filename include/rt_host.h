@@ -52,6 +52,36 @@ void rt_default_globals(float aspect, RtGlobals* g);
 /* main.cpp:443-454: frame_rng <- wang_hash(frame_rng) */
 uint32_t rt_next_frame_rng(uint32_t frame_rng);
 
+/* ---- scene assembly (SCENE CREATION of main.cpp:240-361, generalised to the five configurations of BASELINE.md) ------
+ * "c1" debug_cube.obj 256x256-style test scene, "c2" bunny on a floor under a luminaire, "c3" the Cornell box of
+ * main.cpp:243-361 (boxes Lambert, or Translucent = as shipped), "c4" Cornell walls + translucent bunny (tabulated
+ * BSSRDF), "c5" the instanced bunny field.  The scene owns its meshes; RtGeometry pointers stay valid until
+ * rt_scene_destroy (rt_build_blas only borrows them, main.cpp:344-346).  RtInstance.blas is an index into the scene's
+ * BLAS list: the caller replaces it with the handle rt_build_blas returned for that list entry. */
+typedef struct RtSceneOptions {        /* all zero = the configuration's defaults */
+    uint32_t spp;                      /* samples_per_pixel; 0 = default (c3: 64, c4: 16, else 1)            */
+    uint32_t bounces; int32_t bounces_set; /* bounces_per_sample when bounces_set (default c1, c2: 1, else 4) */
+    int32_t  translucent_boxes;        /* c3: boxes as Shader::Translucent, dipole BSSRDF (main.cpp:311-340,418-422) */
+    int32_t  bssrdf_profile;           /* c4: 0 = skin_0, 1 = skin_1                                          */
+    int32_t  dipole;                   /* c4: dipole instead of the tabulated profile                         */
+    float    sample_radius;            /* c3 translucent / c4: blue-noise radius; 0 = 0.025 (main.cpp:50)     */
+    float    bunny_scale;              /* c4: 0 = 0.6                                                         */
+    uint32_t instances, grid;          /* c5: 0 = 52,743 instances on a 230 x 230 lattice                     */
+} RtSceneOptions;
+typedef struct rt_scene rt_scene;
+rt_scene*         rt_scene_create(const char* config, const char* data_dir, uint32_t width, uint32_t height, const RtSceneOptions* options);
+void              rt_scene_destroy(rt_scene* s);
+int               rt_scene_blas_count(const rt_scene* s);
+int               rt_scene_geometry_count(const rt_scene* s, int blas);
+int               rt_scene_geometry(const rt_scene* s, int blas, int geometry, RtGeometry* out);
+size_t            rt_scene_instance_count(const rt_scene* s);
+const RtInstance* rt_scene_instances(const rt_scene* s);
+const RtGlobals*  rt_scene_globals(const rt_scene* s);      /* defaults of main.cpp:411-422 + the configuration's settings */
+uint32_t          rt_scene_flags(const rt_scene* s);        /* rt_set_flags bits */
+float             rt_scene_sample_radius(const rt_scene* s);/* > 0: call rt_generate_translucent_samples with it */
+int               rt_scene_bssrdf_profile(const rt_scene* s);
+void              rt_scene_seeds(const rt_scene* s, uint32_t* rng_seed, uint32_t* phase_seed);
+
 /* image output (stands in for stbi_write_png, main.cpp:750) */
 int rt_write_png(const char* filename, const uint8_t* rgba8, uint32_t width, uint32_t height); /* 8-bit RGBA like main.cpp:750 */
 int rt_write_ppm(const char* filename, const uint8_t* rgba8, uint32_t width, uint32_t height);

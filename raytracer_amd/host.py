@@ -15,6 +15,28 @@ _lib.rt_mesh_index_count.restype = C.c_size_t
 _lib.rt_aabb_widest.restype = C.c_float
 _lib.rt_triangle_area.restype = C.c_float
 _lib.rt_next_frame_rng.restype = C.c_uint32
+_lib.rt_scene_create.restype = C.c_void_p
+_lib.rt_scene_instances.restype = C.c_void_p
+_lib.rt_scene_globals.restype = C.c_void_p
+_lib.rt_scene_instance_count.restype = C.c_size_t
+_lib.rt_scene_flags.restype = C.c_uint32
+_lib.rt_scene_sample_radius.restype = C.c_float
+for _name in ("rt_scene_destroy", "rt_scene_blas_count", "rt_scene_geometry_count", "rt_scene_geometry", "rt_scene_instance_count",
+              "rt_scene_instances", "rt_scene_globals", "rt_scene_flags", "rt_scene_sample_radius", "rt_scene_bssrdf_profile"):
+    getattr(_lib, _name).argtypes = [C.c_void_p] + ([C.c_int] if _name == "rt_scene_geometry_count" else
+                                                    [C.c_int, C.c_int, C.c_void_p] if _name == "rt_scene_geometry" else [])
+_lib.rt_scene_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+
+
+class RtSceneOptions(C.Structure):
+    """RtSceneOptions of include/rt_host.h"""
+    _fields_ = [("spp", C.c_uint32), ("bounces", C.c_uint32), ("bounces_set", C.c_int32), ("translucent_boxes", C.c_int32),
+                ("bssrdf_profile", C.c_int32), ("dipole", C.c_int32), ("sample_radius", C.c_float), ("bunny_scale", C.c_float),
+                ("instances", C.c_uint32), ("grid", C.c_uint32)]
+
+
+def lib():
+    return _lib
 
 
 def data_path(*parts):

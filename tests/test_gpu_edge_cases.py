@@ -201,3 +201,44 @@ def test_status_codes_instead_of_abort():
         assert lib.rt_read_hit_records(h, C.c_uint32(0), C.c_void_p(buf.ctypes.data)) != _abi.RT_OK  # capture flag not set
     finally:
         rt.close()
+
+
+@pytest.mark.parametrize("split", ["tile", "sample"])
+def test_two_ranks_of_the_product_reproduce_the_one_process_image(split, tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), rehearsed on this box's
+    one GPU (--rehearse: both ranks on GPU 0, gloo for the collective): rank 0's reduced accumulator against the image
+    one process renders from the same frames.  Tile split (C4, with the sample-point pass and the gather): bit for bit.
+    Sample-set split (C2): equal up to the re-association of the frame sum."""
+    import os, subprocess, sys
+    import numpy as np
+    from raytracer_amd import api, scenes, distributed
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "acc.npy")
+    workload = "c4" if split == "tile" else "c2"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse",
+           "--workload", workload, "--split", split, "--width", "256", "--height", "144", "--spp", "2", "--steps", "3",
+           "--warmup", "0", "--no-cpu", "--dump-accumulator", out]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    import json
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["scaling"] == ("strong" if split == "tile" else "weak") and rec["reduce_ms"] > 0
+    got = np.load(out)
+    scene = scenes.cornell_bunny(256, 144, spp=2, bounces=4) if split == "tile" else scenes.bunny(256, 144, spp=1, bounces=1)
+    rt = api.Raytracer(0)
+    try:
+        scene.setup(rt)
+        chain = distributed.FrameChain(scene.globals.frame_rng)
+        for f in range(3 if split == "tile" else 6):
+            distributed.render_frame(rt, scene.globals, f, chain)
+        want = rt.read_accumulator()
+    finally:
+        rt.close()
+    assert want.any()
+    if split == "tile":
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    else:
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-6)

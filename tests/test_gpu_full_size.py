@@ -147,7 +147,7 @@ def test_top_level_rebuilds_between_pipelined_frames(monkeypatch):
     assert np.array_equal(images[0][1], images[1][1]) and images[0][0].any()
 
 
-@pytest.mark.parametrize("case", ["bunny_b1", "bunny_b3", "cornell_spp3", "cornell_bunny"])
+@pytest.mark.parametrize("case", ["bunny_b1", "bunny_b3", "cornell_spp3", "cornell_bunny", "ragged_spp3"])
 def test_images_without_the_hit_tap_match_the_oracle(oracle_mod, case):
     """The ray-by-ray parity tests run with RT_FLAG_CAPTURE_HITS, which keeps the dispatches one at a time and the last
     shade of a frame complete.  The production path -- frames in flight, deferred resolve, lazy render target, and the
@@ -157,7 +157,10 @@ def test_images_without_the_hit_tap_match_the_oracle(oracle_mod, case):
     from raytracer_amd import api
     scene = {"bunny_b1": lambda: scenes.bunny(960, 540, spp=1, bounces=1), "bunny_b3": lambda: scenes.bunny(640, 360, spp=1, bounces=3),
              "cornell_spp3": lambda: scenes.cornell(480, 270, spp=3, bounces=4),
-             "cornell_bunny": lambda: scenes.cornell_bunny(320, 180, spp=2, bounces=3)}[case]()
+             "cornell_bunny": lambda: scenes.cornell_bunny(320, 180, spp=2, bounces=3),
+             # tiles that are only partly inside the image, several samples per pixel, frames in flight: the per-thread
+             # records and the miss / record masks of the deferred resolve on ragged tiles
+             "ragged_spp3": lambda: scenes.bunny(333, 181, spp=3, bounces=2)}[case]()
     gpu = api.Raytracer(0)
     cpu = oracle_mod.Oracle(brute_force=False, threads=16)
     try:
@@ -168,5 +171,50 @@ def test_images_without_the_hit_tap_match_the_oracle(oracle_mod, case):
         assert np.abs(gr - cr).max() <= 1
         if case != "cornell_bunny":   # no tolerance-covered arithmetic without the gather: the same floats, the same bytes
             assert np.array_equal(ga.view(np.uint32), ca.view(np.uint32)) and np.array_equal(gr, cr)
+    finally:
+        gpu.close(); cpu.close()
+
+
+def _tile_subset_mask(width, height, world):
+    """pixels of the 32x32 tiles t with t % world == 0 (rt_set_tile_split(0, world))"""
+    tiles_x = (width + 31) // 32
+    ty, tx = np.divmod(np.arange(height)[:, None] // 32 * tiles_x + np.arange(width)[None, :] // 32, tiles_x)
+    return ((ty * tiles_x + tx) % world) == 0
+
+
+@pytest.mark.parametrize("case", ["c4_skin0", "c4_skin1", "c3_64spp"])
+def test_baseline_sizes_on_the_production_path(oracle_mod, case):
+    """BASELINE.json's C4 (1920x1080, 16 spp, tabulated skin_0 / skin_1 BSSRDF) and C3 (1920x1080, 64 spp) exactly as the
+    bench runs them: no hit tap, two frames in flight, deferred resolve, three frames (accumulator_count 0 and non-zero).
+    The oracle renders an interleaved 1/64 subset of the 32x32 tiles (its own tile split; the sample-point pass is
+    complete in it) and those pixels are compared with the GPU's full-frame accumulator: north_star tolerances for C4
+    (the gather's radiance arithmetic), bit for bit for C3."""
+    from raytracer_amd import api, distributed
+    world = 64
+    if case == "c3_64spp":
+        scene = scenes.cornell(1920, 1080, spp=64, bounces=4)
+    else:
+        scene = scenes.cornell_bunny(1920, 1080, spp=16, bounces=4, profile=int(case[-1]))
+    gpu = api.Raytracer(0)
+    cpu = oracle_mod.Oracle(brute_force=False, threads=16)
+    try:
+        assert scene.setup(gpu) == scene.setup(cpu)
+        cpu.set_tile_split(0, world)
+        for f in range(3):
+            for backend in (gpu, cpu):
+                distributed.render_frame(backend, scene.globals, f, scene.globals.frame_rng)
+        mask = _tile_subset_mask(scene.width, scene.height, world)
+        assert 30000 < int(mask.sum()) < 40000
+        ga, ca = gpu.read_accumulator(), cpu.read_accumulator()
+        assert not ca[~mask].any() and ca[mask].any()
+        if case == "c3_64spp":
+            assert np.array_equal(ga[mask].view(np.uint32), ca[mask].view(np.uint32))
+        else:
+            pu.compare_images(ga[mask], ca[mask])
+            pts_g, pts_c = gpu.read_sample_points(0)[0], cpu.read_sample_points(0)[0]
+            assert np.array_equal(pts_g["position"], pts_c["position"])
+            assert np.allclose(pts_g["payload"], pts_c["payload"], rtol=1e-4, atol=1e-7)
+        gr, cr = gpu.read_render_target().astype(np.int32), cpu.read_render_target().astype(np.int32)
+        assert np.abs(gr[mask] - cr[mask]).max() <= 1
     finally:
         gpu.close(); cpu.close()
