@@ -142,6 +142,10 @@ typedef struct RtStats {
     uint64_t rays_primary;            /* the part of rays_camera traced by bounce-0 launches                                      */
     double   bluenoise_ms;            /* host wall time of the last rt_generate_translucent_samples (it blocks), all instances    */
     uint64_t bluenoise_points;        /* sample points it produced                                                                */
+    uint32_t tlas_depth;              /* inner-node levels of the top-level tree and of the deepest bottom-level tree in it: the  */
+    uint32_t max_blas_depth;          /* traversal stack holds at most tlas_depth + max_blas_depth + 2 entries                    */
+    uint32_t stack_in_lds;            /* 1 = that fits the 17 LDS rows per lane: traversal runs without the global overflow path  */
+    uint32_t _pad;
 } RtStats;
 
 /* rt_set_flags bits */

@@ -65,7 +65,7 @@ struct rt_ctx {
     // TLAS
     u32 n_instances = 0;
     InstRec* d_inst_rec = nullptr; InstShade* d_inst_shade = nullptr; PackedNode* d_tlas_nodes = nullptr; TreeInfo tlas_info = {}; u32* d_tlas_perm = nullptr;
-    int tlas_depth = 0;
+    int tlas_depth = 0, max_blas_depth = 0; bool stack_lds_ok = true; // RT_STACK_LDS=0: always the variant with the global overflow (tuning aid)
     // translucent sample points, all instances concatenated
     u32 n_points = 0;
     RtSamplePoint *d_sp_read = nullptr, *d_sp_write = nullptr; float* d_sp_normal = nullptr; u32* d_sp_slice = nullptr;
@@ -243,6 +243,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.g = c->g;
     a.ray_sort = c->ray_sort ? 1u : 0u;
     a.wave_major = c->wave_major ? 1u : 0u;
+    a.stack_in_lds = (c->stack_lds_ok && c->tlas_depth + c->max_blas_depth + 2 <= 16) ? 1u : 0u; // rows 0..16 of the per-lane LDS stack (rt_kernels.hip)
     a.task_counter = c->d_task_counter; a.persistent_slots = c->persistent_slots;
     // persistent traversal waves pay ~2.5 us per 64-ray task and win back the dispatcher's idle slots; since the dispatched
     // kernels run 6 waves per SIMD in wave-major order that no longer pays on any benchmark scene (k_traverse, rt_kernels.hip)
@@ -500,6 +501,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_RAY_SORT")) c->ray_sort = atoi(v);
     if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
     if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
+    if (const char* v = getenv("RT_STACK_LDS")) c->stack_lds_ok = atoi(v) != 0;
     if (const char* v = getenv("RT_FRAMES_IN_FLIGHT")) c->frames_in_flight = atoi(v);
     if (const char* v = getenv("RT_EXACT_INSTANCE_BOXES")) c->exact_instance_boxes = atoi(v) != 0;
     hipDeviceProp_t prop;
@@ -738,7 +740,7 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
         set_error("rt_build_tlas: BVH too deep for the traversal stack (tlas %d + blas %d)", c->tlas_info.depth, max_blas_depth);
         return RT_ERR_LIMIT;
     }
-    c->tlas_depth = c->tlas_info.depth;
+    c->tlas_depth = c->tlas_info.depth; c->max_blas_depth = max_blas_depth;
     c->n_instances = (u32) n;
     return RT_OK;
 }
@@ -1162,6 +1164,8 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
     out->primary_launches = c->primary_launches; out->primary_launches_timed = c->primary_launches_timed;
     out->primary_ms = c->traverse_primary_ms; out->rays_primary = c->primary_rays;
     out->bluenoise_ms = c->bluenoise_ms; out->bluenoise_points = c->bluenoise_points;
+    out->tlas_depth = (u32) c->tlas_depth; out->max_blas_depth = (u32) c->max_blas_depth;
+    { PassArgs a; fill_pass_args(c, a, false); out->stack_in_lds = a.stack_in_lds; }
     out->blas_build_ms = c->blas_build_ms; out->tlas_build_ms = c->tlas_build_ms;
     out->blas_triangles = c->blas_triangles; out->tlas_instances = c->n_instances;
     return RT_OK;

@@ -318,7 +318,8 @@ __global__ void k_pack_nodes(const Aabb* __restrict__ scene, const BvhNode* __re
         w[2 * k] = l0 | (l1 << 16); w[2 * k + 1] = h0 | (h1 << 16);
     }
     PackedNode pn;
-    pn.lox = w[0]; pn.hix = w[1]; pn.loy = w[2]; pn.hiy = w[3]; pn.loz = w[4]; pn.hiz = w[5]; pn.c0 = nd.c0; pn.c1 = nd.c1;
+    pn.lox = w[0]; pn.hix = w[1]; pn.loy = w[2]; pn.hiy = w[3]; pn.loz = w[4]; pn.hiz = w[5];
+    pn.c0 = nd.c0 >= 0 ? 2 * nd.c0 : nd.c0; pn.c1 = nd.c1 >= 0 ? 2 * nd.c1 : nd.c1; // inner links in 16-byte units (trace_run)
     out[i] = pn;
     if (i == 0) {
         TreeInfo t;

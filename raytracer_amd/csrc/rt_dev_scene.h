@@ -7,7 +7,7 @@
 namespace rtd {
 
 // 64 B: one binary BVH node as the builders write it = the boxes of its two children + two links.
-//   link >= 0 : index of an internal node
+//   link >= 0 : index of an internal node (PackedNode: twice the index, i.e. its offset in 16-byte units)
 //   link <  0 : leaf.  BLAS: ~link = (first_tri << 3) | (tri_count - 1), TLAS: ~link = instance index
 //   an absent child has the box RT_EMPTY_BOX and is never entered
 // Traversal reads the 32-byte PackedNode made from it (below).
@@ -231,7 +231,9 @@ RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, S
     for (;;) {
         // ---- inner nodes ---------------------------------------------------------------------------------------
         while (S.cur >= 0) {
-            const RT_GLOBAL PackedNode* n = S.nodes + S.cur;
+            // links to inner nodes count 16-byte units (k_pack_nodes): base + (cur << 4) is one v_lshl_add_u64, whose shift
+            // goes up to 4; a node index would need a 64-bit shift and a 64-bit add
+            const RT_GLOBAL PackedNode* n = (const RT_GLOBAL PackedNode*) ((const RT_GLOBAL char*) S.nodes + ((unsigned long long) (u32) S.cur << 4));
             const Quad q0 = ldq(n, 0), q1 = ldq(n, 1);
             const int top = st.top();
             if (COUNT) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; }

@@ -34,20 +34,26 @@ static constexpr u32 SEG_RAD_ZERO = 0x80000000u, SEG_FILL_MASK = 0x7fffffffu;
 // conflict-free), deeper entries in a global spill array indexed [entry][queue slot] (touched only by the rare deep
 // path; a private array would be promoted to 32 VGPRs or drag the stack pointer into scratch).  top() and put() touch
 // LDS unconditionally -- indices past the LDS part go to the dump row -- so that the common case has no branch.
+// SPILL = false: the host has checked that the trees are shallow enough for the LDS rows alone (sentinel + top-level depth +
+// marker + bottom-level depth + the row above the top <= LDS_STACK_DEPTH + 1, PassArgs::stack_in_lds): no index clamps, no
+// overflow branches -- a fifth of the node step's instructions on the small scenes (everything but the instance field).
+template <bool SPILL>
 struct LaneStack {
     RT_LDS int* lds;
     RT_GLOBAL int* spill;   // &stack_spill[queue slot]
     u32 spill_stride;
-    int sp;
-    RT_DEV void reset() { lds[0] = RT_TRAVERSAL_DONE; sp = 1; }
-    RT_DEV int top() const { // the entry a pop would return; sp >= 1 while the ray runs
-        const int i = sp - 1;
+    int sp;                 // index of the top entry (>= 0 while the ray runs): top and the row above it share one address + offset
+    RT_DEV void reset() { lds[0] = RT_TRAVERSAL_DONE; sp = 0; }
+    RT_DEV int top() const { // the entry a pop would return
+        const int i = sp;
+        if (!SPILL) return lds[i * TRAVERSE_WAVE];
         int v = lds[(i < LDS_STACK_DEPTH ? i : LDS_STACK_DEPTH) * TRAVERSE_WAVE];
         if (i >= LDS_STACK_DEPTH) v = i < LDS_STACK_DEPTH + OVF_STACK_DEPTH ? spill[(size_t) (i - LDS_STACK_DEPTH) * spill_stride] : RT_TRAVERSAL_DONE;
         return v;
     }
     RT_DEV void put(int v, bool keep) { // stores above the top without moving sp; `keep` = the caller will count it in
-        const int i = sp;
+        const int i = sp + 1;
+        if (!SPILL) { lds[i * TRAVERSE_WAVE] = v; return; }
         lds[(i < LDS_STACK_DEPTH ? i : LDS_STACK_DEPTH) * TRAVERSE_WAVE] = v;
         if (i >= LDS_STACK_DEPTH && keep && i < LDS_STACK_DEPTH + OVF_STACK_DEPTH) spill[(size_t) (i - LDS_STACK_DEPTH) * spill_stride] = v;
     }
@@ -287,7 +293,7 @@ RT_DEV void traverse_counters_flush(const PassArgs& a, const TraverseCounters& c
 // own cache line: atomics on ONE address run at ~90 per microsecond on MI355X, which would make the 32,640 tasks of a
 // 1080p launch cost 0.36 ms.  A wave works through its home partition, then moves to the one with the most tasks left.
 static constexpr u32 TASK_PARTS = 64, TASK_STRIDE = 32; // counters 128 bytes apart; counter TASK_PARTS counts the waves that are done
-template <bool COUNT, int WAVES_PER_SIMD, bool PRIMARY, bool PERSISTENT>
+template <bool COUNT, int WAVES_PER_SIMD, bool PRIMARY, bool PERSISTENT, bool SPILL>
 __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq, u32 sample_index, u32 n_tasks) {
     __shared__ int smem[26 * TRAVERSE_WAVE];
     TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
@@ -353,11 +359,11 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
         }
         if (PERSISTENT) next = (u32) __builtin_amdgcn_readfirstlane((int) next);
         if (active) {
-            LaneStack st; st.lds = (RT_LDS int*) &smem[threadIdx.x]; st.spill = (RT_GLOBAL int*) (a.stack_spill + qi);
-            st.spill_stride = a.n_paths; st.sp = 1;
+            LaneStack<SPILL> st; st.lds = (RT_LDS int*) &smem[threadIdx.x]; st.spill = (RT_GLOBAL int*) (a.stack_spill + qi);
+            st.spill_stride = a.n_paths; st.sp = 0;
             TraceState S;
             trace_begin(a.scene, o, d, a.tmax, S);
-            trace_run<LaneStack, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, S, cnt);
+            trace_run<LaneStack<SPILL>, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, S, cnt);
             // a miss is its instance field alone (-1): the other four words are neither written nor read (k_shade)
             a.hits.inst[qi] = S.best.inst;
             if (S.best.inst >= 0) { a.hits.t[qi] = S.best.t; a.hits.u[qi] = S.best.u; a.hits.v[qi] = S.best.v; a.hits.tri[qi] = S.best.tri; }
@@ -864,14 +870,16 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
     const bool persistent = a.persistent_slots != 0 && !count_traversal && (primary ? (a.persistent & 2u) != 0 : (a.persistent & 1u) != 0) && n_tasks > a.persistent_slots;
     if (persistent) {
         dim3 pgrid(a.persistent_slots);
-        if (primary) hipLaunchKernelGGL((k_traverse<false, 5, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
-        else hipLaunchKernelGGL((k_traverse<false, 5, false, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        if (primary) hipLaunchKernelGGL((k_traverse<false, 5, true, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        else hipLaunchKernelGGL((k_traverse<false, 5, false, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
     } else if (primary) {
-        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-        else hipLaunchKernelGGL((k_traverse<false, 6, true, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        else if (a.stack_in_lds) hipLaunchKernelGGL((k_traverse<false, 6, true, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        else hipLaunchKernelGGL((k_traverse<false, 6, true, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
     } else {
-        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-        else hipLaunchKernelGGL((k_traverse<false, 6, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, false, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        else if (a.stack_in_lds) hipLaunchKernelGGL((k_traverse<false, 6, false, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        else hipLaunchKernelGGL((k_traverse<false, 6, false, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
     }
     RT_HIP(hipGetLastError());
     return RT_OK;

@@ -328,7 +328,8 @@ __global__ void k_sah_finish(const Aabb* __restrict__ scene, const u32* __restri
     if (i == 0) {
         float m = 0.0f;
         for (int k = 0; k < 3; k++) m = fmaxf(m, fmaxf(fabsf(scene->lo[k]), fabsf(scene->hi[k])));
-        nodes[0].bound = m; nodes[0].depth = (int) counters[2] + 1;
+        // counters[2] = depth of the deepest task, and the deepest tasks are leaves: as many inner levels (root = level 1)
+        nodes[0].bound = m; nodes[0].depth = counters[2] > 1u ? (int) counters[2] : 1;
     }
 }
 
