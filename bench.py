@@ -375,7 +375,7 @@ def main():
         # acceleration-structure builds are outside the timed loop: reported separately
         out["build"] = {"last_blas_ms": stats["blas_build_ms"], "blas_triangles_total": stats["blas_triangles"],
                         "tlas_ms": stats["tlas_build_ms"], "tlas_instances": stats["tlas_instances"],
-                        "tlas_depth": stats["tlas_depth"], "max_blas_depth": stats["max_blas_depth"], "stack_in_lds": stats["stack_in_lds"],
+                        "tlas_depth": stats["tlas_depth"], "max_blas_depth": stats["max_blas_depth"], "stack_in_lds": stats["stack_in_lds"], "flat_depth": stats["flat_depth"],
                         "tlas_Minstances_per_s": stats["tlas_instances"] / (stats["tlas_build_ms"] * 1e-3) / 1e6 if stats["tlas_build_ms"] > 0 else None}
         if points:
             # blue-noise sample-point generation (rt_generate_translucent_samples blocks: host wall time), at the scene's

@@ -145,7 +145,8 @@ typedef struct RtStats {
     uint32_t tlas_depth;              /* inner-node levels of the top-level tree and of the deepest bottom-level tree in it: the  */
     uint32_t max_blas_depth;          /* traversal stack holds at most tlas_depth + max_blas_depth + 2 entries                    */
     uint32_t stack_in_lds;            /* 1 = that fits the 17 LDS rows per lane: traversal runs without the global overflow path  */
-    uint32_t _pad;
+    uint32_t flat_depth;              /* > 0: the scene (<= 2 instances) is traversed in ONE tree over all instanced triangles, of   */
+                                      /* this many inner-node levels, instead of the two levels; 0 = two levels */
 } RtStats;
 
 /* rt_set_flags bits */

@@ -37,6 +37,7 @@ struct TranslucentMesh { // raytracing.cpp:49-53 + BluenoisePreprocess (bluenois
 struct Blas {
     RtVertex* d_verts = nullptr; uint16_t* d_indices = nullptr; GeomRec* d_geoms = nullptr; u32* d_tri_geometry = nullptr;
     PackedNode* d_nodes = nullptr; TriRec* d_tris = nullptr; /* inside the d_nodes allocation */ u32* d_perm = nullptr; TreeInfo info = {};
+    u32* d_inv_perm = nullptr; // primitive (index-buffer order) -> TriRec index: what a hit found in the flat tree reports
     std::vector<RtVertex> verts; std::vector<uint16_t> indices; std::vector<GeomRec> geoms;
     u32 n_tris = 0; int depth = 0;
     u32 translucent_ids_index = 0, translucent_ids_count = 0;
@@ -66,6 +67,11 @@ struct rt_ctx {
     u32 n_instances = 0;
     InstRec* d_inst_rec = nullptr; InstShade* d_inst_shade = nullptr; PackedNode* d_tlas_nodes = nullptr; TreeInfo tlas_info = {}; u32* d_tlas_perm = nullptr;
     int tlas_depth = 0, max_blas_depth = 0; bool stack_lds_ok = true; // RT_STACK_LDS=0: always the variant with the global overflow (tuning aid)
+    // flat tree: scenes of at most RT_FLAT_MAX_INSTANCES instances get ONE tree over all instanced triangles besides the two
+    // levels (trace_flat, rt_dev_scene.h); flat_instances = 0: none.  RT_FLAT=0 switches it off (tuning aid, two-level tests).
+    bool flat_enabled = true; u32 flat_instances = 0, flat_tris = 0, flat_first1 = 0;
+    PackedNode* d_flat_nodes = nullptr; FlatTri* d_flat_tris = nullptr; /* inside the d_flat_nodes allocation */ u32* d_flat_perm = nullptr;
+    TreeInfo flat_info = {}; float flat_w2o[RT_FLAT_MAX_INSTANCES][12] = {}; double flat_build_ms = 0;
     // translucent sample points, all instances concatenated
     u32 n_points = 0;
     RtSamplePoint *d_sp_read = nullptr, *d_sp_write = nullptr; float* d_sp_normal = nullptr; u32* d_sp_slice = nullptr;
@@ -264,6 +270,14 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.scene.tlas_nodes = c->d_tlas_nodes; a.scene.insts = c->d_inst_rec;
     for (int k = 0; k < 3; k++) { a.scene.tlas_ctr[k] = c->tlas_info.ctr[k]; a.scene.tlas_inv_h[k] = c->tlas_info.inv_h[k]; }
     a.scene.tlas_bound = c->tlas_info.bound;
+    a.scene.flat_instances = c->flat_instances;
+    if (c->flat_instances) {
+        a.scene.flat_nodes = c->d_flat_nodes; a.scene.flat_tris = c->d_flat_tris; a.scene.flat_copy_bytes = (u32) (c->flat_tris * sizeof(FlatTri));
+        for (int k = 0; k < 3; k++) { a.scene.flat_ctr[k] = c->flat_info.ctr[k]; a.scene.flat_inv_h[k] = c->flat_info.inv_h[k]; }
+        a.scene.flat_bound = c->flat_info.bound;
+        a.scene.flat_first1 = c->flat_first1;
+        memcpy(a.scene.flat_w2o, c->flat_w2o, sizeof c->flat_w2o);
+    }
     a.shade.insts = c->d_inst_shade; a.shade.slot_to_ti = c->d_slot_to_ti; a.shade.slot_count = c->slot_count;
     a.shade.slices = c->d_slices;
     a.q[0] = c->q[0]; a.q[1] = c->q[1]; a.hits = c->hits; a.ps = c->ps; a.gq = c->gq;
@@ -425,7 +439,54 @@ void phase_sequence(u32 seed, u32 count, u32* seq) {
 
 void free_blas(Blas& b) {
     dev_free(b.d_verts); dev_free(b.d_indices); dev_free(b.d_geoms); dev_free(b.d_tri_geometry);
-    dev_free(b.d_nodes); b.d_tris = nullptr; dev_free(b.d_perm);
+    dev_free(b.d_nodes); b.d_tris = nullptr; dev_free(b.d_perm); dev_free(b.d_inv_perm);
+}
+
+void free_flat_tree(rt_ctx* c) {
+    dev_free(c->d_flat_nodes); c->d_flat_tris = nullptr; dev_free(c->d_flat_perm);
+    c->flat_instances = 0; c->flat_tris = 0; c->flat_build_ms = 0;
+}
+
+// One tree over the world boxes of all instanced triangles, for scenes of one or two instances (every BASELINE
+// configuration but the instance field): the walk then has no instance entries (trace_flat, rt_dev_scene.h).  Built with
+// the same builders as the two levels; the triangles keep their object-space vertices (S7: the test runs there).
+// Not built -- the two-level walk stays -- when the scene is larger than that or the tree too deep for the LDS stack.
+int build_flat_tree(rt_ctx* c, const RtInstance* instances, int n, const std::vector<InstRec>& rec) {
+    if (!c->flat_enabled || n > RT_FLAT_MAX_INSTANCES) return RT_OK;
+    FlatSources src; memset(&src, 0, sizeof src);
+    uint64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        const Blas& b = c->blas[instances[i].blas];
+        FlatSource& fs = src.s[i];
+        fs.verts = b.d_verts; fs.indices = b.d_indices; fs.inv_perm = b.d_inv_perm;
+        memcpy(fs.o2w, instances[i].transform, 64);
+        fs.first = (u32) total; fs.n_tris = b.n_tris;
+        total += b.n_tris;
+    }
+    src.n = (u32) n;
+    if (total > RT_FLAT_MAX_TRIS) return RT_OK;
+    const u32 nt = (u32) total;
+    u32 n_nodes = n > 1 ? 1u : 0u, largest = 0;
+    for (int i = 0; i < n; i++) { n_nodes += src.s[i].n_tris > 1 ? src.s[i].n_tris - 1 : 1; largest = std::max(largest, src.s[i].n_tris); }
+    int rc = lbvh_workspace_reserve(c->lbvh, largest); if (rc) return rc;
+    RT_HIP(hipMalloc(&c->d_flat_nodes, n_nodes * sizeof(PackedNode) + 3 * (size_t) nt * sizeof(FlatTri)));
+    c->d_flat_tris = (FlatTri*) (c->d_flat_nodes + n_nodes);
+    RT_HIP(hipMalloc(&c->d_flat_perm, 4 * (size_t) nt));
+    BvhNode* d_join = nullptr; Aabb* d_sub = nullptr;
+    RT_HIP(hipMalloc(&d_join, n_nodes * sizeof(BvhNode) + (RT_FLAT_MAX_INSTANCES + 1) * sizeof(Aabb)));
+    d_sub = (Aabb*) (d_join + n_nodes);
+    RT_HIP(hipEventRecord(c->build_ev[0], c->stream));
+    rc = lbvh_flat_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, src, d_join, d_sub, c->d_flat_perm, c->d_flat_tris, c->d_flat_nodes);
+    if (rc) { (void) hipStreamSynchronize(c->stream); (void) hipFree(d_join); return rc; }
+    RT_HIP(hipEventRecord(c->build_ev[1], c->stream));
+    RT_HIP(hipMemcpyAsync(&c->flat_info, c->lbvh.tree_info, sizeof c->flat_info, hipMemcpyDeviceToHost, c->stream));
+    { hipError_t e = hipStreamSynchronize(c->stream); (void) hipFree(d_join); RT_HIP(e); }
+    float ms = 0; RT_HIP(hipEventElapsedTime(&ms, c->build_ev[0], c->build_ev[1]));
+    // k_traverse<.., FLAT> keeps the whole stack in its 26 LDS rows: sentinel + one entry per level + the row above the top
+    if (c->flat_info.depth + 2 > 26) { free_flat_tree(c); return RT_OK; }
+    for (int i = 0; i < n; i++) memcpy(c->flat_w2o[i], rec[i].world_to_object, 48);
+    c->flat_instances = (u32) n; c->flat_tris = nt; c->flat_build_ms = ms; c->flat_first1 = n > 1 ? src.s[1].first : nt;
+    return RT_OK;
 }
 
 // device half of rt_build_blas: uploads the concatenated geometry and builds the bottom-level tree on c->stream
@@ -439,6 +500,7 @@ int build_blas_on_device(rt_ctx* c, Blas& b, const std::vector<u32>& tri_geometr
     RT_HIP(hipMalloc(&b.d_nodes, n_nodes * sizeof(PackedNode) + 3 * (size_t) b.n_tris * sizeof(TriRec))); // three copies of the triangles (TriRec)
     b.d_tris = (TriRec*) (b.d_nodes + n_nodes);
     RT_HIP(hipMalloc(&b.d_perm, b.n_tris * 4));
+    RT_HIP(hipMalloc(&b.d_inv_perm, b.n_tris * 4));
     RT_HIP(hipMemcpyAsync(b.d_verts, b.verts.data(), b.verts.size() * sizeof(RtVertex), hipMemcpyHostToDevice, c->stream));
     RT_HIP(hipMemcpyAsync(b.d_indices, b.indices.data(), b.indices.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
     RT_HIP(hipMemcpyAsync(b.d_geoms, b.geoms.data(), b.geoms.size() * sizeof(GeomRec), hipMemcpyHostToDevice, c->stream));
@@ -448,6 +510,7 @@ int build_blas_on_device(rt_ctx* c, Blas& b, const std::vector<u32>& tri_geometr
     rc = lbvh_triangle_boxes(c->stream, c->lbvh, b.d_verts, b.d_indices, b.n_tris); if (rc) return rc;
     rc = lbvh_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, b.n_tris, RT_LEAF_MAX_TRIS, false, b.d_nodes, b.d_perm); if (rc) return rc;
     rc = lbvh_write_trirecs(c->stream, b.d_perm, b.d_verts, b.d_indices, b.d_tri_geometry, b.d_geoms, b.n_tris, b.d_tris); if (rc) return rc;
+    rc = lbvh_invert_perm(c->stream, b.d_perm, b.n_tris, b.d_inv_perm); if (rc) return rc;
     RT_HIP(hipEventRecord(c->build_ev[1], c->stream));
     RT_HIP(hipMemcpyAsync(&b.info, c->lbvh.tree_info, sizeof b.info, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream)); // host arrays are borrowed only for this call
@@ -502,6 +565,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
     if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
     if (const char* v = getenv("RT_STACK_LDS")) c->stack_lds_ok = atoi(v) != 0;
+    if (const char* v = getenv("RT_FLAT")) c->flat_enabled = atoi(v) != 0;
     if (const char* v = getenv("RT_FRAMES_IN_FLIGHT")) c->frames_in_flight = atoi(v);
     if (const char* v = getenv("RT_EXACT_INSTANCE_BOXES")) c->exact_instance_boxes = atoi(v) != 0;
     hipDeviceProp_t prop;
@@ -548,6 +612,7 @@ void rt_destroy(rt_ctx* c) {
     for (auto& m : c->translucent_meshes) dev_free(m.d_partial_areas);
     free_sample_points(c);
     dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
+    free_flat_tree(c);
     dev_free(c->d_task_counter);
     dev_free(c->d_accumulator); dev_free(c->d_render_target); dev_free(c->d_capture); dev_free(c->d_arena);
     dev_free(c->d_seg_count); dev_free(c->d_stats); dev_free(c->d_table[0]); dev_free(c->d_table[1]);
@@ -718,6 +783,7 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
         max_blas_depth = std::max(max_blas_depth, b.depth);
     }
     dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
+    free_flat_tree(c);
     c->n_instances = 0; c->tlas_depth = 0; // no top level until this call has succeeded: a failure below leaves rt_dispatch_rays answering RT_ERR_STATE
     u32 n_nodes = n > 1 ? (u32) n - 1 : 1;
     RT_HIP(hipMalloc(&c->d_inst_rec, sizeof(InstRec) * n));
@@ -740,6 +806,9 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
         set_error("rt_build_tlas: BVH too deep for the traversal stack (tlas %d + blas %d)", c->tlas_info.depth, max_blas_depth);
         return RT_ERR_LIMIT;
     }
+    rc = build_flat_tree(c, instances, n, rec);
+    if (rc != RT_OK) { free_flat_tree(c); return rc; }
+    c->tlas_build_ms += c->flat_build_ms;
     c->tlas_depth = c->tlas_info.depth; c->max_blas_depth = max_blas_depth;
     c->n_instances = (u32) n;
     return RT_OK;
@@ -1166,6 +1235,7 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
     out->bluenoise_ms = c->bluenoise_ms; out->bluenoise_points = c->bluenoise_points;
     out->tlas_depth = (u32) c->tlas_depth; out->max_blas_depth = (u32) c->max_blas_depth;
     { PassArgs a; fill_pass_args(c, a, false); out->stack_in_lds = a.stack_in_lds; }
+    out->flat_depth = c->flat_instances ? (uint32_t) c->flat_info.depth : 0u;
     out->blas_build_ms = c->blas_build_ms; out->tlas_build_ms = c->tlas_build_ms;
     out->blas_triangles = c->blas_triangles; out->tlas_instances = c->n_instances;
     return RT_OK;

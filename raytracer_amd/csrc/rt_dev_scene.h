@@ -64,10 +64,32 @@ struct alignas(16) InstRec {
     float pad;
 };
 
+// Flat scenes (a handful of instances, rt_build_tlas): ONE tree over the world-space boxes of all instanced triangles.
+// 48 B: a triangle of that tree in leaf order, vertices in its instance's OBJECT space (the triangle test runs there, S7),
+// three copies by coordinate order like TriRec.  The tree keeps the instances in separate subtrees (lbvh_flat_build), and
+// the triangles of instance 0 come first: a leaf (links as in a BLAS) belongs to instance 1 iff its first triangle is at
+// or after SceneView::flat_first1.
+struct alignas(16) FlatTri {
+    float v0[3], v1[3], v2[3];
+    u32 prim_global; // primitive index in the BLAS index buffer: the tie-break key of S5
+    u32 tri;         // TriRec index inside the instance's BLAS (what the hit record names)
+    u32 inst;        // index into the rt_build_tlas array
+};
+#define RT_FLAT_MAX_INSTANCES 2
+#define RT_FLAT_MAX_TRIS (1u << 20) // triangles of all instances together (leaf links keep 24 bits for the first one)
+
 struct SceneView {
     const PackedNode* tlas_nodes;
     const InstRec* insts;
     float tlas_ctr[3], tlas_inv_h[3], tlas_bound;
+    // flat tree (flat_instances = 0: none, traverse the two levels)
+    const PackedNode* flat_nodes;
+    const FlatTri* flat_tris;
+    u32 flat_copy_bytes;     // size of one copy of the FlatTri array
+    u32 flat_instances;
+    u32 flat_first1;         // first triangle of instance 1 (the triangle count when there is one instance)
+    float flat_ctr[3], flat_inv_h[3], flat_bound;
+    float flat_w2o[RT_FLAT_MAX_INSTANCES][12]; // world_to_object of the instances (InstRec), here so that they arrive as scalars
 };
 
 struct HitOut {
@@ -213,50 +235,67 @@ RT_DEV void trace_begin(const SceneView& sc, f3 o, f3 d, float tmax, TraceState&
     S.cur = finite ? 0 : RT_TRAVERSAL_DONE;
 }
 
+// One step down the tree: fetches node `cur` (>= 0), tests the two child boxes against [tmin, best_t] and returns the link
+// to go on with -- the nearer child hit (the other one goes on the stack), or the top of the stack when neither is.
+// Straight-line code: the entry a pop would return is read together with the node (it is needed by the lanes whose
+// boxes both miss), the far child is stored above the top of the stack whether or not it is kept, and the stack pointer
+// moves by (both hit) - (none hit).  A wave pays every path that any of its lanes takes, so the branchy form (pop /
+// descend / push as separate exec-masked regions, ~60 scalar instructions per step) cost the sum of all of them.
+template <class Stack, bool COUNT>
+RT_DEV int node_step(const RT_GLOBAL PackedNode* nodes, const BoxRay& r, int cur, float tmin, float best_t, Stack& st, TraverseCounters& cnt) {
+    // links to inner nodes count 16-byte units (k_pack_nodes): base + (cur << 4) is one v_lshl_add_u64, whose shift
+    // goes up to 4; a node index would need a 64-bit shift and a 64-bit add
+    const RT_GLOBAL PackedNode* n = (const RT_GLOBAL PackedNode*) ((const RT_GLOBAL char*) nodes + ((unsigned long long) (u32) cur << 4));
+    const Quad q0 = ldq(n, 0), q1 = ldq(n, 1);
+    const int top = st.top();
+    if (COUNT) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; }
+    // entry / exit planes of both children, one packed word per axis
+    const u32 nwx = as_u32(r.px ? q0.x : q0.y), fwx = as_u32(r.px ? q0.y : q0.x);
+    const u32 nwy = as_u32(r.py ? q0.z : q0.w), fwy = as_u32(r.py ? q0.w : q0.z);
+    const u32 nwz = as_u32(r.pz ? q1.x : q1.y), fwz = as_u32(r.pz ? q1.y : q1.x);
+    const float e0 = fmaxf(fmaxf(__builtin_fmaf(half_lo(nwx), r.idx, r.cnx), __builtin_fmaf(half_lo(nwy), r.idy, r.cny)), __builtin_fmaf(half_lo(nwz), r.idz, r.cnz));
+    const float x0 = fminf(fminf(__builtin_fmaf(half_lo(fwx), r.idx, r.cfx), __builtin_fmaf(half_lo(fwy), r.idy, r.cfy)), __builtin_fmaf(half_lo(fwz), r.idz, r.cfz));
+    const float e1 = fmaxf(fmaxf(__builtin_fmaf(half_hi(nwx), r.idx, r.cnx), __builtin_fmaf(half_hi(nwy), r.idy, r.cny)), __builtin_fmaf(half_hi(nwz), r.idz, r.cnz));
+    const float x1 = fminf(fminf(__builtin_fmaf(half_hi(fwx), r.idx, r.cfx), __builtin_fmaf(half_hi(fwy), r.idy, r.cfy)), __builtin_fmaf(half_hi(fwz), r.idz, r.cfz));
+    // hit iff the padded slab intervals and [tmin, best t] have a common point
+    const bool h0 = fmaxf(e0, tmin) <= fminf(x0, best_t);
+    const bool h1 = fmaxf(e1, tmin) <= fminf(x1, best_t);
+    const int c0 = (int) as_u32(q1.z), c1 = (int) as_u32(q1.w);
+    const bool both = h0 && h1, any = h0 || h1, first0 = e0 <= e1;
+    st.put(first0 ? c1 : c0, both);       // the far child, kept only when both boxes are hit
+    int next = h0 ? c0 : c1;              // the only child hit ...
+    next = both ? (first0 ? c0 : c1) : next; // ... or the nearer of the two
+    st.sp += (both ? 1 : 0) - (any ? 0 : 1);
+    return any ? next : top;
+}
+
+// the closest-hit update of one triangle candidate (S5, S6): minimum t inside (tmin, best t], ties to the lowest
+// (instance, primitive); written without short-circuit branches
+struct ClosestHit {
+    float t, u_num, v_num, det; // u = u_num / det, v = v_num / det once the ray is finished (S4)
+    int inst, tri; u32 prim_global; bool have;
+};
+RT_DEV void closest_hit_update(ClosestHit& b, bool hit, float t, float vn, float wn, float det, float tmin, int inst, int tri, u32 prim_global) {
+    const bool in_range = t > tmin; // t < tmax follows from `better`: b.t starts at tmax and only decreases
+    const bool first_of_tie = (inst < b.inst) | ((inst == b.inst) & (prim_global < b.prim_global));
+    const bool better = (t < b.t) | (b.have & (t == b.t) & first_of_tie);
+    if (hit & in_range & better) { b.t = t; b.u_num = vn; b.v_num = wn; b.det = det; b.inst = inst; b.tri = tri; b.prim_global = prim_global; b.have = true; }
+}
+
 // Runs the ray to the end; S.best is then final (t = +inf for a miss).
 // `Stack` provides reset() / top() / put(v, really) / push(v) / pop(), the stack pointer `sp` and a side store of nine
 // floats (save_side / load_side) for the top-level box-test constants; COUNT enables the
 // traversal counters.  The bottom stack entry is a RT_TRAVERSAL_DONE sentinel, so a pop never has to ask whether the
 // stack is empty, and "back to the top level" (RT_STACK_MARKER) and "finished" are handled like leaves.
 //
-// The node step is straight-line code: the entry a pop would return is read together with the node (it is needed by
-// the lanes whose boxes both miss), the far child is stored above the top of the stack whether or not it is kept, and
-// the stack pointer moves by (both hit) - (none hit).  A wave pays every path that any of its lanes takes, so the
-// branchy form (pop / descend / push as separate exec-masked regions, ~60 scalar instructions per step) cost the sum
-// of all of them on most steps.
+// (node step: node_step above)
 template <class Stack, bool COUNT>
 RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, Stack& st, TraceState& S, TraverseCounters& cnt) {
     st.reset();
     { const BoxRay& b = S.br; const float v[9] = { b.idx, b.idy, b.idz, b.cnx, b.cny, b.cnz, b.cfx, b.cfy, b.cfz }; st.save_side(v); }
     for (;;) {
         // ---- inner nodes ---------------------------------------------------------------------------------------
-        while (S.cur >= 0) {
-            // links to inner nodes count 16-byte units (k_pack_nodes): base + (cur << 4) is one v_lshl_add_u64, whose shift
-            // goes up to 4; a node index would need a 64-bit shift and a 64-bit add
-            const RT_GLOBAL PackedNode* n = (const RT_GLOBAL PackedNode*) ((const RT_GLOBAL char*) S.nodes + ((unsigned long long) (u32) S.cur << 4));
-            const Quad q0 = ldq(n, 0), q1 = ldq(n, 1);
-            const int top = st.top();
-            if (COUNT) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; }
-            const BoxRay& r = S.br;
-            // entry / exit planes of both children, one packed word per axis
-            const u32 nwx = as_u32(r.px ? q0.x : q0.y), fwx = as_u32(r.px ? q0.y : q0.x);
-            const u32 nwy = as_u32(r.py ? q0.z : q0.w), fwy = as_u32(r.py ? q0.w : q0.z);
-            const u32 nwz = as_u32(r.pz ? q1.x : q1.y), fwz = as_u32(r.pz ? q1.y : q1.x);
-            const float e0 = fmaxf(fmaxf(__builtin_fmaf(half_lo(nwx), r.idx, r.cnx), __builtin_fmaf(half_lo(nwy), r.idy, r.cny)), __builtin_fmaf(half_lo(nwz), r.idz, r.cnz));
-            const float x0 = fminf(fminf(__builtin_fmaf(half_lo(fwx), r.idx, r.cfx), __builtin_fmaf(half_lo(fwy), r.idy, r.cfy)), __builtin_fmaf(half_lo(fwz), r.idz, r.cfz));
-            const float e1 = fmaxf(fmaxf(__builtin_fmaf(half_hi(nwx), r.idx, r.cnx), __builtin_fmaf(half_hi(nwy), r.idy, r.cny)), __builtin_fmaf(half_hi(nwz), r.idz, r.cnz));
-            const float x1 = fminf(fminf(__builtin_fmaf(half_hi(fwx), r.idx, r.cfx), __builtin_fmaf(half_hi(fwy), r.idy, r.cfy)), __builtin_fmaf(half_hi(fwz), r.idz, r.cfz));
-            // hit iff the padded slab intervals and [tmin, best t] have a common point
-            const bool h0 = fmaxf(e0, tmin) <= fminf(x0, S.best.t);
-            const bool h1 = fmaxf(e1, tmin) <= fminf(x1, S.best.t);
-            const int c0 = (int) as_u32(q1.z), c1 = (int) as_u32(q1.w);
-            const bool both = h0 && h1, any = h0 || h1, first0 = e0 <= e1;
-            st.put(first0 ? c1 : c0, both);       // the far child, kept only when both boxes are hit
-            int next = h0 ? c0 : c1;              // the only child hit ...
-            next = both ? (first0 ? c0 : c1) : next; // ... or the nearer of the two
-            S.cur = any ? next : top;
-            st.sp += (both ? 1 : 0) - (any ? 0 : 1);
-        }
+        while (S.cur >= 0) S.cur = node_step<Stack, COUNT>(S.nodes, S.br, S.cur, tmin, S.best.t, st, cnt);
         if (S.cur == RT_TRAVERSAL_DONE) break;
         if (S.cur == RT_STACK_MARKER) {
             // ---- the instance is finished: back to the top level ---------------------------------------------------
@@ -294,6 +333,64 @@ RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, S
     }
     if (S.have_hit) { S.best.u = S.best.u / S.det; S.best.v = S.best.v / S.det; } // S4: u = V / det, v = W / det
     else S.best.t = inf_f32();
+}
+
+// ---- flat scenes: one tree, no instance entry --------------------------------------------------------------------------
+// The same answer as trace_run (S4-S7: every triangle is tested in its instance's object space with the ray taken there
+// by world_to_object), found in ONE world-space tree over all instanced triangles (rt_build_tlas builds it when the scene
+// has at most RT_FLAT_MAX_INSTANCES instances: every BASELINE configuration but the instance field).  What the two-level
+// walk pays per instance ENTRY -- transform, ray shear with three divisions, box-test constants, the way back to the top
+// level: ~200 vector instructions, executed by the whole wave whenever one lane enters -- is paid here once per instance
+// and ray, by all lanes together, before the walk: the RayPrep of each of the K instances stays in registers and a leaf
+// picks the one its tag names.  The box test runs in world space all the way down (one BoxRay), the node base is the
+// same for all lanes, and the walk has no level changes (no marker, no side store).
+template <int K>
+struct FlatPreps { RayPrep rp[K]; };
+template <int K>
+RT_DEV RayPrep flat_pick(const FlatPreps<K>& p, u32 inst) {
+    if (K == 1) return p.rp[0];
+    const bool one = inst != 0u;
+    const RayPrep &a = p.rp[0], &b = p.rp[K - 1];
+    RayPrep r;
+    r.o = mk3(one ? b.o.x : a.o.x, one ? b.o.y : a.o.y, one ? b.o.z : a.o.z);
+    r.kz = one ? b.kz : a.kz; r.flip = one ? b.flip : a.flip;
+    r.sx = one ? b.sx : a.sx; r.sy = one ? b.sy : a.sy; r.sz = one ? b.sz : a.sz;
+    return r;
+}
+template <int K, class Stack, bool COUNT>
+RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, Stack& st, HitOut& out, TraverseCounters& cnt) {
+    static_assert(K >= 1 && K <= RT_FLAT_MAX_INSTANCES && RT_FLAT_MAX_INSTANCES == 2, "flat_pick selects between two preparations");
+    ClosestHit best; best.t = tmax; best.u_num = 0.0f; best.v_num = 0.0f; best.det = 1.0f; best.inst = -1; best.tri = -1; best.prim_global = 0; best.have = false;
+    const float big = 3.0e38f; // NaN or infinite rays miss without a walk (trace_begin)
+    const bool finite = fabsf(o.x) <= big && fabsf(o.y) <= big && fabsf(o.z) <= big && fabsf(d.x) <= big && fabsf(d.y) <= big && fabsf(d.z) <= big;
+    const BoxRay br = make_box_ray(o, d, sc.flat_bound, mk3(sc.flat_ctr[0], sc.flat_ctr[1], sc.flat_ctr[2]), mk3(sc.flat_inv_h[0], sc.flat_inv_h[1], sc.flat_inv_h[2]));
+    FlatPreps<K> preps;
+    for (int i = 0; i < K; i++) preps.rp[i] = prepare_ray(xform_point43(sc.flat_w2o[i], o), xform_dir43(sc.flat_w2o[i], d)); // the matrices are kernel arguments: scalar loads
+    st.reset();
+    int cur = finite ? 0 : RT_TRAVERSAL_DONE;
+    const RT_GLOBAL PackedNode* nodes = (const RT_GLOBAL PackedNode*) sc.flat_nodes;
+    for (;;) {
+        while (cur >= 0) cur = node_step<Stack, COUNT>(nodes, br, cur, tmin, best.t, st, cnt);
+        if (cur == RT_TRAVERSAL_DONE) break;
+        // ---- leaf: up to 8 triangles of one instance ---------------------------------------------------------------
+        const u32 v = (u32) ~cur;
+        const u32 first = v >> 3, count = (v & 7u) + 1u;
+        const u32 inst = K > 1 && first >= sc.flat_first1 ? 1u : 0u;
+        const RayPrep rp = flat_pick<K>(preps, inst);
+        const RT_GLOBAL char* tris0 = (const RT_GLOBAL char*) sc.flat_tris + ((size_t) first * sizeof(FlatTri) + (size_t) ((u32) rp.kz * sc.flat_copy_bytes));
+        for (u32 k = 0; k < count; k++) {
+            const RT_GLOBAL FlatTri* tr = (const RT_GLOBAL FlatTri*) (tris0 + k * sizeof(FlatTri));
+            const Quad a = ldq(tr, 0), b = ldq(tr, 1), c = ldq(tr, 2);
+            if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
+            float t = 0.0f, vn = 0.0f, wn = 0.0f, det = 1.0f;
+            const bool hit = intersect_triangle(rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, vn, wn, det);
+            closest_hit_update(best, hit, t, vn, wn, det, tmin, (int) inst, (int) as_u32(c.z), as_u32(c.y));
+        }
+        cur = st.pop();
+    }
+    out.inst = best.inst; out.tri = best.tri; out.prim_global = best.prim_global;
+    if (best.have) { out.t = best.t; out.u = best.u_num / best.det; out.v = best.v_num / best.det; } // S4: u = V / det, v = W / det
+    else { out.t = inf_f32(); out.u = 0.0f; out.v = 0.0f; }
 }
 
 } // namespace rtd

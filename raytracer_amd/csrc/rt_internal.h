@@ -91,6 +91,15 @@ int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace*
 int lbvh_write_trirecs(hipStream_t s, const u32* perm, const RtVertex* verts, const uint16_t* indices,
                        const u32* tri_geometry, const rtd::GeomRec* geoms, u32 n_tris, rtd::TriRec* out);
 
+// flat tree over the triangles of all instances of a small scene (rt_dev_scene.h: FlatTri, trace_flat)
+struct FlatSource { const RtVertex* verts; const uint16_t* indices; const u32* inv_perm; /* primitive -> TriRec index of the BLAS */ float o2w[16]; u32 first, n_tris; };
+struct FlatSources { FlatSource s[RT_FLAT_MAX_INSTANCES]; u32 n; }; // s[k].first = triangles of the instances before k
+int lbvh_invert_perm(hipStream_t s, const u32* perm, u32 n, u32* inv);
+// builds the flat tree: `join` (scratch) holds 1 + sum of max(n_i - 1, 1) BvhNodes, `sub_boxes` (scratch) RT_FLAT_MAX_INSTANCES + 1 boxes,
+// `perm` all triangles, `tris` three copies of them, `nodes_out` as many nodes as `join`; TreeInfo ends in w.tree_info
+int lbvh_flat_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace* sw, int builder, float sah_tri, const FlatSources& src,
+                    rtd::BvhNode* join, rtd::Aabb* sub_boxes, u32* perm, rtd::FlatTri* tris, rtd::PackedNode* nodes_out);
+
 // ---- wavefront pipeline (rt_kernels.hip) ---------------------------------------------------------------------
 struct RayQueue { float *ox, *oy, *oz, *dx, *dy, *dz; u32* path; };
 struct HitBuf { float *t, *u, *v; int *inst, *tri; };

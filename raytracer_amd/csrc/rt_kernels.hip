@@ -293,7 +293,9 @@ RT_DEV void traverse_counters_flush(const PassArgs& a, const TraverseCounters& c
 // own cache line: atomics on ONE address run at ~90 per microsecond on MI355X, which would make the 32,640 tasks of a
 // 1080p launch cost 0.36 ms.  A wave works through its home partition, then moves to the one with the most tasks left.
 static constexpr u32 TASK_PARTS = 64, TASK_STRIDE = 32; // counters 128 bytes apart; counter TASK_PARTS counts the waves that are done
-template <bool COUNT, int WAVES_PER_SIMD, bool PRIMARY, bool PERSISTENT, bool SPILL>
+// FLAT = K > 0: the scene has K <= RT_FLAT_MAX_INSTANCES instances and one tree over all their triangles (trace_flat,
+// rt_dev_scene.h); the stack then has all 26 LDS rows to itself (no side store; the host checks the depth).
+template <bool COUNT, int WAVES_PER_SIMD, bool PRIMARY, bool PERSISTENT, bool SPILL, int FLAT = 0>
 __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq, u32 sample_index, u32 n_tasks) {
     __shared__ int smem[26 * TRAVERSE_WAVE];
     TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
@@ -361,12 +363,18 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
         if (active) {
             LaneStack<SPILL> st; st.lds = (RT_LDS int*) &smem[threadIdx.x]; st.spill = (RT_GLOBAL int*) (a.stack_spill + qi);
             st.spill_stride = a.n_paths; st.sp = 0;
-            TraceState S;
-            trace_begin(a.scene, o, d, a.tmax, S);
-            trace_run<LaneStack<SPILL>, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, S, cnt);
+            HitOut best;
+            if (FLAT > 0) {
+                trace_flat<(FLAT > 0 ? FLAT : 1), LaneStack<SPILL>, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, best, cnt);
+            } else {
+                TraceState S;
+                trace_begin(a.scene, o, d, a.tmax, S);
+                trace_run<LaneStack<SPILL>, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, S, cnt);
+                best = S.best;
+            }
             // a miss is its instance field alone (-1): the other four words are neither written nor read (k_shade)
-            a.hits.inst[qi] = S.best.inst;
-            if (S.best.inst >= 0) { a.hits.t[qi] = S.best.t; a.hits.u[qi] = S.best.u; a.hits.v[qi] = S.best.v; a.hits.tri[qi] = S.best.tri; }
+            a.hits.inst[qi] = best.inst;
+            if (best.inst >= 0) { a.hits.t[qi] = best.t; a.hits.u[qi] = best.u; a.hits.v[qi] = best.v; a.hits.tri[qi] = best.tri; }
         }
         if (!PERSISTENT) break;
         task = next * TASK_PARTS + part < n_tasks ? next * TASK_PARTS + part : n_tasks;
@@ -872,6 +880,20 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
         dim3 pgrid(a.persistent_slots);
         if (primary) hipLaunchKernelGGL((k_traverse<false, 5, true, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
         else hipLaunchKernelGGL((k_traverse<false, 5, false, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
+    } else if (a.scene.flat_instances == 1u || a.scene.flat_instances == 2u) {
+        // one tree over the triangles of all (one or two) instances; count_traversal: the same walk with the counters on
+        const bool two = a.scene.flat_instances == 2u;
+        if (primary) {
+            if (count_traversal) { if (two) hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+                                   else hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks); }
+            else if (two) hipLaunchKernelGGL((k_traverse<false, 6, true, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+            else hipLaunchKernelGGL((k_traverse<false, 6, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        } else {
+            if (count_traversal) { if (two) hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+                                   else hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks); }
+            else if (two) hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+            else hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        }
     } else if (primary) {
         if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
         else if (a.stack_in_lds) hipLaunchKernelGGL((k_traverse<false, 6, true, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);

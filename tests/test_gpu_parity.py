@@ -115,3 +115,43 @@ def test_corner_instance_boxes_still_work(oracle_mod, monkeypatch):
     """TLAS boxes from the corners of the BLAS box (the fallback for very large vertex counts)"""
     monkeypatch.setenv("RT_EXACT_INSTANCE_BOXES", "0")
     _check_scene(scenes.bunny_field(96, 54, spp=1, bounces=2, grid=8, count=40), oracle_mod, brute_force=False)
+
+
+@pytest.mark.parametrize("flat", ["0", "1"])
+def test_flat_and_two_level_walks_agree_with_the_oracle(oracle_mod, monkeypatch, flat):
+    """scenes of one or two instances are traced in ONE world-space tree (RT_FLAT=1, the default: rt_dev_scene.h
+    trace_flat) or through the two levels like every other scene (RT_FLAT=0): same hits, t, u, v, RNG, bit for bit.
+    Covers one instance (Cornell), two (bunny on a floor: rotated Y-up mesh; translucent bunny in the room with the
+    sample-point pass) and a one-triangle instance (its tree is a single node)."""
+    from raytracer_amd import api
+    monkeypatch.setenv("RT_FLAT", flat)                   # read at rt_create
+    rt = api.Raytracer(0)
+    try:
+        scenes.bunny(64, 36, spp=1, bounces=1).setup(rt)
+        assert (rt.get_stats()["flat_depth"] > 0) == (flat == "1")
+    finally:
+        rt.close()
+    _check_scene(scenes.cornell(96, 54, spp=2, bounces=3), oracle_mod)
+    _check_scene(scenes.bunny(128, 72, spp=1, bounces=3), oracle_mod, frames=2)
+    _check_scene(scenes.cornell_bunny(96, 54, spp=2, bounces=2, sample_radius=0.06), oracle_mod)
+    s = scenes.debug_cube(64, 64, spp=1, bounces=2)
+    from raytracer_amd import host
+    tri_v = np.zeros(3, dtype=_abi.VERTEX_DTYPE)
+    tri_v["position"] = [(-0.4, -0.3, 0.5), (0.4, -0.3, 0.5), (0.0, 0.5, 0.6)]
+    tri_v["normal"] = [(0.0, 0.0, -1.0)] * 3
+    s.blas[0] = [scenes._geo(tri_v, np.array([0, 2, 1], dtype=np.uint16), _abi.RT_SHADER_LAMBERT, (0.8, 0.8, 0.8))]
+    s.instances[0] = (host.affine_transform(1.3, 0.7, (0.1, -0.05, 0.0)), 0)
+    _check_scene(s, oracle_mod)
+
+
+def test_three_instances_keep_the_two_levels():
+    """the flat tree is for scenes of at most two instances; a third keeps the two-level walk"""
+    from raytracer_amd import api, host
+    s = scenes.debug_cube(64, 64, spp=1, bounces=1)
+    s.instances.append((host.affine_transform(0.2, 1.0, (0.5, 0.5, 0.3)), 0))
+    rt = api.Raytracer(0)
+    try:
+        s.setup(rt)
+        assert rt.get_stats()["flat_depth"] == 0
+    finally:
+        rt.close()
