@@ -69,7 +69,7 @@ struct rt_ctx {
     int tlas_depth = 0, max_blas_depth = 0; bool stack_lds_ok = true; // RT_STACK_LDS=0: always the variant with the global overflow (tuning aid)
     // flat tree: scenes of at most RT_FLAT_MAX_INSTANCES instances get ONE tree over all instanced triangles besides the two
     // levels (trace_flat, rt_dev_scene.h); flat_instances = 0: none.  RT_FLAT=0 switches it off (tuning aid, two-level tests).
-    bool flat_enabled = true; u32 flat_instances = 0, flat_tris = 0, flat_first1 = 0;
+    bool flat_enabled = true, flat_waves8 = true; u32 flat_instances = 0, flat_tris = 0, flat_first1 = 0;
     PackedNode* d_flat_nodes = nullptr; FlatTri* d_flat_tris = nullptr; /* inside the d_flat_nodes allocation */ u32* d_flat_perm = nullptr;
     TreeInfo flat_info = {}; float flat_w2o[RT_FLAT_MAX_INSTANCES][12] = {}; double flat_build_ms = 0;
     // translucent sample points, all instances concatenated
@@ -271,6 +271,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     for (int k = 0; k < 3; k++) { a.scene.tlas_ctr[k] = c->tlas_info.ctr[k]; a.scene.tlas_inv_h[k] = c->tlas_info.inv_h[k]; }
     a.scene.tlas_bound = c->tlas_info.bound;
     a.scene.flat_instances = c->flat_instances;
+    a.flat_waves8 = (c->flat_waves8 && c->flat_instances == 1 && c->flat_info.depth + 2 <= 20) ? 1u : 0u;
     if (c->flat_instances) {
         a.scene.flat_nodes = c->d_flat_nodes; a.scene.flat_tris = c->d_flat_tris; a.scene.flat_copy_bytes = (u32) (c->flat_tris * sizeof(FlatTri));
         for (int k = 0; k < 3; k++) { a.scene.flat_ctr[k] = c->flat_info.ctr[k]; a.scene.flat_inv_h[k] = c->flat_info.inv_h[k]; }
@@ -566,6 +567,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
     if (const char* v = getenv("RT_STACK_LDS")) c->stack_lds_ok = atoi(v) != 0;
     if (const char* v = getenv("RT_FLAT")) c->flat_enabled = atoi(v) != 0;
+    if (const char* v = getenv("RT_FLAT_WAVES8")) c->flat_waves8 = atoi(v) != 0;
     if (const char* v = getenv("RT_FRAMES_IN_FLIGHT")) c->frames_in_flight = atoi(v);
     if (const char* v = getenv("RT_EXACT_INSTANCE_BOXES")) c->exact_instance_boxes = atoi(v) != 0;
     hipDeviceProp_t prop;

@@ -365,7 +365,13 @@ RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, 
     const bool finite = fabsf(o.x) <= big && fabsf(o.y) <= big && fabsf(o.z) <= big && fabsf(d.x) <= big && fabsf(d.y) <= big && fabsf(d.z) <= big;
     const BoxRay br = make_box_ray(o, d, sc.flat_bound, mk3(sc.flat_ctr[0], sc.flat_ctr[1], sc.flat_ctr[2]), mk3(sc.flat_inv_h[0], sc.flat_inv_h[1], sc.flat_inv_h[2]));
     FlatPreps<K> preps;
-    for (int i = 0; i < K; i++) preps.rp[i] = prepare_ray(xform_point43(sc.flat_w2o[i], o), xform_dir43(sc.flat_w2o[i], d)); // the matrices are kernel arguments: scalar loads
+    for (int i = 0; i < K; i++) {
+        preps.rp[i] = prepare_ray(xform_point43(sc.flat_w2o[i], o), xform_dir43(sc.flat_w2o[i], d)); // the matrices are kernel arguments: scalar loads
+#if defined(__HIP_DEVICE_COMPILE__)
+        // computed here, once per ray: left alone the compiler keeps d[kz] instead of 1 / d[kz] and divides again at every leaf
+        asm volatile("" : "+v"(preps.rp[i].sx), "+v"(preps.rp[i].sy), "+v"(preps.rp[i].sz));
+#endif
+    }
     st.reset();
     int cur = finite ? 0 : RT_TRAVERSAL_DONE;
     const RT_GLOBAL PackedNode* nodes = (const RT_GLOBAL PackedNode*) sc.flat_nodes;

@@ -143,6 +143,7 @@ struct PassArgs {
     u32 lazy_render_target;      // the resolve leaves the render target alone (rt_api.hip derives it from the accumulator when it is read)
     u32 defer_resolve;           // fused camera pass: finished paths leave their pixel's sample sum in ps.sum_* for k_frame_resolve
     u32 stack_in_lds;            // the trees are shallow enough for the LDS rows of the traversal stack alone (LaneStack<false>)
+    u32 flat_waves8;             // one-instance flat tree shallow enough for 20 LDS rows: traversal kernels at 8 waves per SIMD
     u32 wave_major;              // queued traverse launches: task -> (segment, wave) mapping, see k_traverse (RT_WAVE_MAJOR)
     u32 ray_sort;                // fused camera pass: survivors of a bounce are grouped by direction octant inside their segment (RT_RAY_SORT)
     SlotState st[2];             // fused camera pass: path state by queue slot

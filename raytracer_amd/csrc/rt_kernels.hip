@@ -297,7 +297,7 @@ static constexpr u32 TASK_PARTS = 64, TASK_STRIDE = 32; // counters 128 bytes ap
 // rt_dev_scene.h); the stack then has all 26 LDS rows to itself (no side store; the host checks the depth).
 template <bool COUNT, int WAVES_PER_SIMD, bool PRIMARY, bool PERSISTENT, bool SPILL, int FLAT = 0>
 __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq, u32 sample_index, u32 n_tasks) {
-    __shared__ int smem[26 * TRAVERSE_WAVE];
+    __shared__ int smem[(WAVES_PER_SIMD == 8 ? 20 : 26) * TRAVERSE_WAVE]; // 8 waves per SIMD = 32 per CU: 5 KB each of the 160 KB
     TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
     u32 part = blockIdx.x % TASK_PARTS;
     // next task of partition `p`, or n_tasks when it has none left (wave-uniform; costs one atomic round trip)
@@ -887,11 +887,13 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
             if (count_traversal) { if (two) hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
                                    else hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks); }
             else if (two) hipLaunchKernelGGL((k_traverse<false, 6, true, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+            else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
             else hipLaunchKernelGGL((k_traverse<false, 6, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
         } else {
             if (count_traversal) { if (two) hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
                                    else hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks); }
             else if (two) hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+            else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
             else hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
         }
     } else if (primary) {
