@@ -201,6 +201,47 @@ RT_DEV bool intersect_triangle(const RayPrep& r, f3 p0, f3 p1, f3 p2, float& t_o
     return true;
 }
 
+// One triangle candidate against the closest hit so far (S4-S6): intersect_triangle and the closest-hit rule in one
+// piece, written as nested conditions.  Each condition is a wave-level branch (an exec mask: scalar work), and what sits
+// behind it -- the division, the tie rule, the seven moves of an update -- costs vector instructions only when some lane
+// gets there; the values a rejected candidate would have carried are never made up.  The exact-zero test of the edge
+// functions is one min3 of magnitudes instead of three compares.  Same operands, same results as the two separate steps.
+struct ClosestHit {
+    float t, u_num, v_num, det; // u = u_num / det, v = v_num / det once the ray is finished (S4); t starts at TMax
+    int inst, tri;              // inst < 0: no hit yet
+    u32 prim_global;
+};
+RT_DEV void triangle_candidate(const RayPrep& r, f3 p0, f3 p1, f3 p2, float tmin, int inst, int tri, u32 prim_global, ClosestHit& best) {
+    f3 A = p0 - r.o, B = p1 - r.o, C = p2 - r.o;
+    float Akz = A.z, Bkz = B.z, Ckz = C.z;
+    float Ax = A.x - r.sx * Akz, Ay = A.y - r.sy * Akz;
+    float Bx = B.x - r.sx * Bkz, By = B.y - r.sy * Bkz;
+    float Cx = C.x - r.sx * Ckz, Cy = C.y - r.sy * Ckz;
+    Ax = as_f32(as_u32(Ax) ^ r.flip); Bx = as_f32(as_u32(Bx) ^ r.flip); Cx = as_f32(as_u32(Cx) ^ r.flip); // kx and ky exchanged (see RayPrep)
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (fminf(fminf(fabsf(U), fabsf(V)), fabsf(W)) == 0.0f) { // U == 0 || V == 0 || W == 0 (a NaN is not a zero either way)
+        double CxBy = (double) Cx * (double) By, CyBx = (double) Cy * (double) Bx;
+        U = (float) (CxBy - CyBx);
+        double AxCy = (double) Ax * (double) Cy, AyCx = (double) Ay * (double) Cx;
+        V = (float) (AxCy - AyCx);
+        double BxAy = (double) Bx * (double) Ay, ByAx = (double) By * (double) Ax;
+        W = (float) (BxAy - ByAx);
+    }
+    if (U < 0.0f || V < 0.0f || W < 0.0f) return;
+    const float det = U + V + W;
+    if (det == 0.0f) return;
+    const float Az = r.sz * Akz, Bz = r.sz * Bkz, Cz = r.sz * Ckz;
+    const float T = U * Az + V * Bz + W * Cz;
+    const float t = T / det;
+    if (!(t > tmin)) return;    // t < TMax follows from the rule below: best.t starts at TMax and only decreases
+    bool better = t < best.t;
+    if (t == best.t && best.inst >= 0) // exact tie: the lowest (instance, primitive) wins (S5)
+        better = inst < best.inst || (inst == best.inst && prim_global < best.prim_global);
+    if (better) { best.t = t; best.u_num = V; best.v_num = W; best.det = det; best.inst = inst; best.tri = tri; best.prim_global = prim_global; }
+}
+
 // ---- BSSRDF ---------------------------------------------------------------------------------------------------
 // S8: linear filtering of the zero-bordered 1-D table at texel coordinate u*N - 0.5 (raytracing.hlsl:275)
 RT_DEV f3 sample_bssrdf_table(const float* tab /* rgb interleaved */, int n, float u) {

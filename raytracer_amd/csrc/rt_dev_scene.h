@@ -175,11 +175,11 @@ RT_DEV Quad ldq(const RT_GLOBAL void* base, int quad_index) { return ((const RT_
 //
 // The per-ray state is a struct so that kernels can set a ray up (trace_begin) and run it (trace_run) separately.
 struct TraceState {
-    HitOut best;
-    bool have_hit, bottom;
+    HitOut best;     // filled in when the ray is finished
+    ClosestHit ch;   // the closest hit so far (triangle_candidate, rt_dev_math.h)
+    bool bottom;
     int cur_inst;  // instance being traversed (bottom level)
     int cur;       // node link in hand, RT_TRAVERSAL_DONE when the ray is finished
-    float det;     // denominator of best.u / best.v, which hold the numerators until the ray is finished
     const RT_GLOBAL PackedNode* nodes;
     const RT_GLOBAL TriRec* tris;
     BoxRay br;
@@ -222,8 +222,8 @@ RT_DEV void trace_resume_top_level(const SceneView& sc, const Stack& st, TraceSt
 }
 
 RT_DEV void trace_begin(const SceneView& sc, f3 o, f3 d, float tmax, TraceState& S) {
-    S.best.t = tmax; S.best.u = 0.0f; S.best.v = 0.0f; S.best.inst = -1; S.best.tri = -1; S.best.prim_global = 0;
-    S.have_hit = false; S.cur_inst = -1; S.tris = nullptr; S.det = 1.0f;
+    S.ch.t = tmax; S.ch.u_num = 0.0f; S.ch.v_num = 0.0f; S.ch.det = 1.0f; S.ch.inst = -1; S.ch.tri = -1; S.ch.prim_global = 0;
+    S.cur_inst = -1; S.tris = nullptr;
     S.rp.o = o; S.rp.kz = 2; S.rp.flip = 0u; S.rp.sx = S.rp.sy = S.rp.sz = 0.0f;
     trace_top_level(sc, o, d, S);
     // a NaN in the ray makes every triangle test fail (S4 compares with NaN are false): the answer is a miss, and
@@ -269,19 +269,6 @@ RT_DEV int node_step(const RT_GLOBAL PackedNode* nodes, const BoxRay& r, int cur
     return any ? next : top;
 }
 
-// the closest-hit update of one triangle candidate (S5, S6): minimum t inside (tmin, best t], ties to the lowest
-// (instance, primitive); written without short-circuit branches
-struct ClosestHit {
-    float t, u_num, v_num, det; // u = u_num / det, v = v_num / det once the ray is finished (S4)
-    int inst, tri; u32 prim_global; bool have;
-};
-RT_DEV void closest_hit_update(ClosestHit& b, bool hit, float t, float vn, float wn, float det, float tmin, int inst, int tri, u32 prim_global) {
-    const bool in_range = t > tmin; // t < tmax follows from `better`: b.t starts at tmax and only decreases
-    const bool first_of_tie = (inst < b.inst) | ((inst == b.inst) & (prim_global < b.prim_global));
-    const bool better = (t < b.t) | (b.have & (t == b.t) & first_of_tie);
-    if (hit & in_range & better) { b.t = t; b.u_num = vn; b.v_num = wn; b.det = det; b.inst = inst; b.tri = tri; b.prim_global = prim_global; b.have = true; }
-}
-
 // Runs the ray to the end; S.best is then final (t = +inf for a miss).
 // `Stack` provides reset() / top() / put(v, really) / push(v) / pop(), the stack pointer `sp` and a side store of nine
 // floats (save_side / load_side) for the top-level box-test constants; COUNT enables the
@@ -295,7 +282,7 @@ RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, S
     { const BoxRay& b = S.br; const float v[9] = { b.idx, b.idy, b.idz, b.cnx, b.cny, b.cnz, b.cfx, b.cfy, b.cfz }; st.save_side(v); }
     for (;;) {
         // ---- inner nodes ---------------------------------------------------------------------------------------
-        while (S.cur >= 0) S.cur = node_step<Stack, COUNT>(S.nodes, S.br, S.cur, tmin, S.best.t, st, cnt);
+        while (S.cur >= 0) S.cur = node_step<Stack, COUNT>(S.nodes, S.br, S.cur, tmin, S.ch.t, st, cnt);
         if (S.cur == RT_TRAVERSAL_DONE) break;
         if (S.cur == RT_STACK_MARKER) {
             // ---- the instance is finished: back to the top level ---------------------------------------------------
@@ -316,23 +303,14 @@ RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, S
                 const RT_GLOBAL TriRec* tr = S.tris + first + k;
                 Quad a = ldq(tr, 0), b = ldq(tr, 1), c = ldq(tr, 2);
                 if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
-                float t = 0.0f, vn = 0.0f, wn = 0.0f, det = 1.0f;
-                const bool hit = intersect_triangle(S.rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, vn, wn, det);
-                const u32 prim_global = as_u32(c.y);
-                // closest hit, ties to the lowest (instance, primitive); written without short-circuit branches
-                const bool in_range = t > tmin; // t < tmax follows from `better`: best.t starts at tmax and only decreases
-                const bool first_of_tie = (S.cur_inst < S.best.inst) | ((S.cur_inst == S.best.inst) & (prim_global < S.best.prim_global));
-                const bool better = (t < S.best.t) | (S.have_hit & (t == S.best.t) & first_of_tie);
-                if (hit & in_range & better) {
-                    S.best.t = t; S.best.u = vn; S.best.v = wn; S.det = det; S.best.inst = S.cur_inst; S.best.tri = first + k;
-                    S.best.prim_global = prim_global; S.have_hit = true;
-                }
+                triangle_candidate(S.rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), tmin, S.cur_inst, first + k, as_u32(c.y), S.ch);
             }
             S.cur = st.pop();
         }
     }
-    if (S.have_hit) { S.best.u = S.best.u / S.det; S.best.v = S.best.v / S.det; } // S4: u = V / det, v = W / det
-    else S.best.t = inf_f32();
+    S.best.inst = S.ch.inst; S.best.tri = S.ch.tri; S.best.prim_global = S.ch.prim_global;
+    if (S.ch.inst >= 0) { S.best.t = S.ch.t; S.best.u = S.ch.u_num / S.ch.det; S.best.v = S.ch.v_num / S.ch.det; } // S4: u = V / det, v = W / det
+    else { S.best.t = inf_f32(); S.best.u = 0.0f; S.best.v = 0.0f; }
 }
 
 // ---- flat scenes: one tree, no instance entry --------------------------------------------------------------------------
@@ -360,7 +338,7 @@ RT_DEV RayPrep flat_pick(const FlatPreps<K>& p, u32 inst) {
 template <int K, class Stack, bool COUNT>
 RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, Stack& st, HitOut& out, TraverseCounters& cnt) {
     static_assert(K >= 1 && K <= RT_FLAT_MAX_INSTANCES && RT_FLAT_MAX_INSTANCES == 2, "flat_pick selects between two preparations");
-    ClosestHit best; best.t = tmax; best.u_num = 0.0f; best.v_num = 0.0f; best.det = 1.0f; best.inst = -1; best.tri = -1; best.prim_global = 0; best.have = false;
+    ClosestHit best; best.t = tmax; best.u_num = 0.0f; best.v_num = 0.0f; best.det = 1.0f; best.inst = -1; best.tri = -1; best.prim_global = 0;
     const float big = 3.0e38f; // NaN or infinite rays miss without a walk (trace_begin)
     const bool finite = fabsf(o.x) <= big && fabsf(o.y) <= big && fabsf(o.z) <= big && fabsf(d.x) <= big && fabsf(d.y) <= big && fabsf(d.z) <= big;
     const BoxRay br = make_box_ray(o, d, sc.flat_bound, mk3(sc.flat_ctr[0], sc.flat_ctr[1], sc.flat_ctr[2]), mk3(sc.flat_inv_h[0], sc.flat_inv_h[1], sc.flat_inv_h[2]));
@@ -388,14 +366,12 @@ RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, 
             const RT_GLOBAL FlatTri* tr = (const RT_GLOBAL FlatTri*) (tris0 + k * sizeof(FlatTri));
             const Quad a = ldq(tr, 0), b = ldq(tr, 1), c = ldq(tr, 2);
             if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
-            float t = 0.0f, vn = 0.0f, wn = 0.0f, det = 1.0f;
-            const bool hit = intersect_triangle(rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, vn, wn, det);
-            closest_hit_update(best, hit, t, vn, wn, det, tmin, (int) inst, (int) as_u32(c.z), as_u32(c.y));
+            triangle_candidate(rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), tmin, (int) inst, (int) as_u32(c.z), as_u32(c.y), best);
         }
         cur = st.pop();
     }
     out.inst = best.inst; out.tri = best.tri; out.prim_global = best.prim_global;
-    if (best.have) { out.t = best.t; out.u = best.u_num / best.det; out.v = best.v_num / best.det; } // S4: u = V / det, v = W / det
+    if (best.inst >= 0) { out.t = best.t; out.u = best.u_num / best.det; out.v = best.v_num / best.det; } // S4: u = V / det, v = W / det
     else { out.t = inf_f32(); out.u = 0.0f; out.v = 0.0f; }
 }
 
