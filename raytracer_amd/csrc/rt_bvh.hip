@@ -306,7 +306,7 @@ int lbvh_invert_perm(hipStream_t s, const u32* perm, u32 n, u32* inv) {
 }
 
 static int lbvh_build_impl(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace* sw, int builder, float sah_tri, u32 n, int leaf_max, bool tlas, BvhNode* nodes_out, u32* perm_out);
-__global__ void k_pack_nodes(const Aabb* __restrict__ scene, const BvhNode* __restrict__ nodes, u32 n_nodes, PackedNode* __restrict__ out, TreeInfo* __restrict__ info);
+__global__ void k_pack_nodes(const Aabb* __restrict__ scene, const BvhNode* __restrict__ nodes, u32 n_nodes, PackedNode* __restrict__ out, TreeInfo* __restrict__ info, int link_scale);
 
 // One tree per instance over the world boxes of its triangles, with the same builders as the two levels, joined under one
 // top node (two instances) and packed in the frame of the box of everything.  A tree over all triangles together came out
@@ -327,7 +327,7 @@ int lbvh_flat_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorks
                            (const Aabb*) w.scene_box, join, sub_boxes + i, perm + src.s[i].first);
     }
     if (src.n > 1) hipLaunchKernelGGL(k_flat_join_top, dim3(1), dim3(64), 0, s, join, sub_boxes, base[0], base[1]);
-    hipLaunchKernelGGL(k_pack_nodes, grid_for(total_nodes), dim3(BT), 0, s, (const Aabb*) (sub_boxes + (src.n > 1 ? 2 : 0)), (const BvhNode*) join, total_nodes, nodes_out, w.tree_info);
+    hipLaunchKernelGGL(k_pack_nodes, grid_for(total_nodes), dim3(BT), 0, s, (const Aabb*) (sub_boxes + (src.n > 1 ? 2 : 0)), (const BvhNode*) join, total_nodes, nodes_out, w.tree_info, 32); // inner links are byte offsets (trace_flat: one base for all lanes)
     hipLaunchKernelGGL(k_flat_tris, grid_for(3 * (size_t) total_tris), dim3(BT), 0, s, src, (const u32*) perm, total_tris, tris);
     RT_HIP(hipGetLastError());
     return RT_OK;
@@ -414,7 +414,7 @@ RT_DEV void pack_planes(float lo, float hi, float ctr, float inv_h, u32& qlo, u3
     qlo = half_floor(a); qhi = half_ceil(b);
 }
 __global__ void k_pack_nodes(const Aabb* __restrict__ scene, const BvhNode* __restrict__ nodes, u32 n_nodes,
-                             PackedNode* __restrict__ out, TreeInfo* __restrict__ info) {
+                             PackedNode* __restrict__ out, TreeInfo* __restrict__ info, int link_scale) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     float ctr[3], inv_h[3];
@@ -429,7 +429,8 @@ __global__ void k_pack_nodes(const Aabb* __restrict__ scene, const BvhNode* __re
     }
     PackedNode pn;
     pn.lox = w[0]; pn.hix = w[1]; pn.loy = w[2]; pn.hiy = w[3]; pn.loz = w[4]; pn.hiz = w[5];
-    pn.c0 = nd.c0 >= 0 ? 2 * nd.c0 : nd.c0; pn.c1 = nd.c1 >= 0 ? 2 * nd.c1 : nd.c1; // inner links in 16-byte units (trace_run)
+    // inner links: link_scale = 2: 16-byte units (trace_run: base + (link << 4) is one instruction), 32: byte offsets (trace_flat)
+    pn.c0 = nd.c0 >= 0 ? link_scale * nd.c0 : nd.c0; pn.c1 = nd.c1 >= 0 ? link_scale * nd.c1 : nd.c1;
     out[i] = pn;
     if (i == 0) {
         TreeInfo t;
@@ -444,7 +445,7 @@ int lbvh_build(hipStream_t s, LbvhWorkspace& w, PlocWorkspace* pw, SahWorkspace*
     int rc = lbvh_build_impl(s, w, pw, sw, builder, sah_tri, n, leaf_max, tlas, w.tree_nodes, perm_out);
     if (rc != RT_OK) return rc;
     const u32 n_nodes = n > 1 ? n - 1 : 1;
-    hipLaunchKernelGGL(k_pack_nodes, grid_for(n_nodes), dim3(BT), 0, s, w.scene_box, (const BvhNode*) w.tree_nodes, n_nodes, nodes_out, w.tree_info);
+    hipLaunchKernelGGL(k_pack_nodes, grid_for(n_nodes), dim3(BT), 0, s, w.scene_box, (const BvhNode*) w.tree_nodes, n_nodes, nodes_out, w.tree_info, 2);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

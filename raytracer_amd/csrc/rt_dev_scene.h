@@ -241,11 +241,13 @@ RT_DEV void trace_begin(const SceneView& sc, f3 o, f3 d, float tmax, TraceState&
 // boxes both miss), the far child is stored above the top of the stack whether or not it is kept, and the stack pointer
 // moves by (both hit) - (none hit).  A wave pays every path that any of its lanes takes, so the branchy form (pop /
 // descend / push as separate exec-masked regions, ~60 scalar instructions per step) cost the sum of all of them.
-template <class Stack, bool COUNT>
+// BYTE_LINKS: `nodes` is the same for all lanes and inner links are byte offsets (flat tree): the load takes the base as
+// a scalar and the link as its 32-bit offset, no address arithmetic at all.
+template <class Stack, bool COUNT, bool BYTE_LINKS = false>
 RT_DEV int node_step(const RT_GLOBAL PackedNode* nodes, const BoxRay& r, int cur, float tmin, float best_t, Stack& st, TraverseCounters& cnt) {
-    // links to inner nodes count 16-byte units (k_pack_nodes): base + (cur << 4) is one v_lshl_add_u64, whose shift
-    // goes up to 4; a node index would need a 64-bit shift and a 64-bit add
-    const RT_GLOBAL PackedNode* n = (const RT_GLOBAL PackedNode*) ((const RT_GLOBAL char*) nodes + ((unsigned long long) (u32) cur << 4));
+    // otherwise links to inner nodes count 16-byte units (k_pack_nodes): base + (cur << 4) is one v_lshl_add_u64, whose
+    // shift goes up to 4; a node index would need a 64-bit shift and a 64-bit add
+    const RT_GLOBAL PackedNode* n = (const RT_GLOBAL PackedNode*) ((const RT_GLOBAL char*) nodes + (BYTE_LINKS ? (unsigned long long) (u32) cur : ((unsigned long long) (u32) cur << 4)));
     const Quad q0 = ldq(n, 0), q1 = ldq(n, 1);
     const int top = st.top();
     if (COUNT) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; }
@@ -354,7 +356,7 @@ RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, 
     int cur = finite ? 0 : RT_TRAVERSAL_DONE;
     const RT_GLOBAL PackedNode* nodes = (const RT_GLOBAL PackedNode*) sc.flat_nodes;
     for (;;) {
-        while (cur >= 0) cur = node_step<Stack, COUNT>(nodes, br, cur, tmin, best.t, st, cnt);
+        while (cur >= 0) cur = node_step<Stack, COUNT, true>(nodes, br, cur, tmin, best.t, st, cnt);
         if (cur == RT_TRAVERSAL_DONE) break;
         // ---- leaf: up to 8 triangles of one instance ---------------------------------------------------------------
         const u32 v = (u32) ~cur;
