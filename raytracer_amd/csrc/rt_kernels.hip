@@ -577,20 +577,23 @@ struct alignas(16) GatherPoint { float px, py, pz, pad0, wx, wy, wz, pad1; };
 // -1, entries 2..n+1 the texels, entries n+2 and n+3 zero again (tab_fill_lds).  Same arithmetic as
 // sample_bssrdf_table for every finite coordinate; the border replaces the range checks (a clamp of the texel index
 // instead of seven compares, seven selects and a branch): outside the table both texels are 0 and so is 0 + f * 0.
+// (radiance only, 1e-4: the filter is one fused multiply-add per channel.  The texel coordinate keeps the oracle's two
+// roundings: x is ~2000 where the profile ends, an ulp of it is 1.2e-4 of a texel, and the texels there are steep --
+// a fused u n - 0.5 put one pixel of the C4 test 1.6e-4 off)
 RT_DEV f3 sample_bssrdf_table_lds(const float4* tab, int n, float u) {
     const float x = u * (float) n - 0.5f;
     const float fl = floorf(x);
     const float f = x - fl;
     const int k0 = (int) fminf(fmaxf(fl, -2.0f), (float) n) + 2; // 0 .. n + 2
     const float4 t0 = tab[k0], t1 = tab[k0 + 1];
-    const f3 ta = mk3(t0.x, t0.y, t0.z), tb = mk3(t1.x, t1.y, t1.z);
-    return ta + f * (tb - ta);
+    return mk3(__builtin_fmaf(f, t1.x - t0.x, t0.x), __builtin_fmaf(f, t1.y - t0.y, t0.y), __builtin_fmaf(f, t1.z - t0.z, t0.z));
 }
+// `factor` (fudge / scale^2, raytracing.hlsl:276) is multiplied into the texels here, once, instead of into every filtered value
 template <int BLOCK>
-RT_DEV void tab_fill_lds(float4* tab, const float* table, int n) {
+RT_DEV void tab_fill_lds(float4* tab, const float* table, int n, float factor) {
     for (int t = threadIdx.x; t < n + 4; t += BLOCK) {
         const int k = t - 2;
-        tab[t] = (k >= 0 && k < n) ? make_float4(table[3 * k], table[3 * k + 1], table[3 * k + 2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        tab[t] = (k >= 0 && k < n) ? make_float4(factor * table[3 * k], factor * table[3 * k + 1], factor * table[3 * k + 2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
     const int my_ti = active ? g.ti[i] : -1;
     const float scale = a.g.translucent_bssrdf_scale;
     if (MODE == 1)
-        tab_fill_lds<GATHER_BLOCK>(s_tab, a.bssrdf_table, a.bssrdf_texels);
+        tab_fill_lds<GATHER_BLOCK>(s_tab, a.bssrdf_table, a.bssrdf_texels, a.fudge / (scale * scale));
     // radiance-only arithmetic (covered by the 1e-4 tolerance): fudge / scale^2 is folded into one
     // factor, and the dipole uses the hardware sqrt / rcp / exp2.  The table coordinate radius / scale stays (all but)
     // correctly rounded -- near the end of the profile's support the texels are ~1e-7 and an ulp of the coordinate is a
@@ -698,9 +701,8 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
                     f3 bs;
                     if (MODE != 0) {
                         const float coord = div_by_shared(radius, scale, inv_scale);
-                        f3 tv = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, coord)
-                                          : sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, coord);
-                        bs = fudge_over_z * tv;                                                                  // :272-276
+                        bs = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, coord)            // :272-276 (the factor is in the LDS texels)
+                                       : fudge_over_z * sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, coord);
                     } else if (GREY) { float v = dipole_eval_fast(cr, radius); bs = mk3(v, v, v); }               // :278-301
                     else bs = mk3(dipole_eval_fast(cr, radius), dipole_eval_fast(cg, radius), dipole_eval_fast(cb, radius));
                     return Term{bs, mk3(gp.wx, gp.wy, gp.wz)};
@@ -783,7 +785,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather_hg(PassArgs a) {
         i = lo * SEG + (jj - a.goff[lo]);
     }
     if (MODE == 1) {
-        tab_fill_lds<GATHER_BLOCK>(s_tab, a.bssrdf_table, a.bssrdf_texels);
+        tab_fill_lds<GATHER_BLOCK>(s_tab, a.bssrdf_table, a.bssrdf_texels, a.fudge / (a.g.translucent_bssrdf_scale * a.g.translucent_bssrdf_scale)); // as in k_gather
         __syncthreads();
     }
     if (!active) return;
@@ -809,9 +811,8 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather_hg(PassArgs a) {
     auto bssrdf = [&](float radius) -> f3 {
         if (MODE != 0) {
             const float coord = div_by_shared(radius, scale, inv_scale);
-            f3 tv = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, coord)
-                              : sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, coord);
-            return fudge_over_z * tv;
+            return MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, coord)
+                             : fudge_over_z * sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, coord);
         }
         if (grey) { float v = dipole_eval_fast(cr, radius); return mk3(v, v, v); }
         return mk3(dipole_eval_fast(cr, radius), dipole_eval_fast(cg, radius), dipole_eval_fast(cb, radius));
