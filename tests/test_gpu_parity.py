@@ -155,3 +155,27 @@ def test_three_instances_keep_the_two_levels():
         assert rt.get_stats()["flat_depth"] == 0
     finally:
         rt.close()
+
+
+def test_top_level_rebuilds_switch_between_the_flat_tree_and_the_two_levels(oracle_mod):
+    """one context, three top levels in a row: two instances (flat tree), three (two levels: the flat tree is freed), one
+    (flat tree again, single subtree) -- after every rebuild the hits equal the oracle's on the same instances"""
+    from raytracer_amd import api, host
+    scene = scenes.bunny(96, 54, spp=1, bounces=2)
+    extra = (host.affine_transform(0.35, 2.0, (0.6, -0.4, 0.1)), 0)
+    gpu = api.Raytracer(0)
+    cpu = oracle_mod.Oracle(brute_force=True, threads=8)
+    try:
+        pu.run_pair(scene, gpu, cpu, frames=1)
+        for k, (instances, flat) in enumerate([(scene.instances, True), (scene.instances + [extra], False), (scene.instances[:1], True)]):
+            if k:  # the same BLAS handles (0 and 1 on both backends: built in the same order by run_pair)
+                for backend in (gpu, cpu):
+                    backend.build_tlas([(m, b) for m, b in instances])
+                    g = backend.get_globals(); g.accumulator_count = 0; backend.set_globals(g)
+                    backend.dispatch_rays()
+            assert (gpu.get_stats()["flat_depth"] > 0) == flat
+            for b in range(scene.globals.bounces_per_sample + 1):
+                pu.compare_hits(gpu.read_hit_records(b), cpu.read_hit_records(b), b)
+            pu.compare_images(gpu.read_accumulator(), cpu.read_accumulator())
+    finally:
+        gpu.close(); cpu.close()
