@@ -144,7 +144,8 @@ typedef struct RtStats {
     uint64_t bluenoise_points;        /* sample points it produced                                                                */
     uint32_t tlas_depth;              /* inner-node levels of the top-level tree and of the deepest bottom-level tree in it: the  */
     uint32_t max_blas_depth;          /* traversal stack holds at most tlas_depth + max_blas_depth + 2 entries                    */
-    uint32_t stack_in_lds;            /* 1 = that fits the 17 LDS rows per lane: traversal runs without the global overflow path  */
+    uint32_t stack_in_lds;            /* 1 = that fits the 17 LDS rows per lane of the 6-wave kernels, 2 = the 33 rows of the 5-wave  */
+                                      /* kernels: traversal runs without the global overflow path; 0 = with it                     */
     uint32_t flat_depth;              /* > 0: the scene (<= 2 instances) is traversed in ONE tree over all instanced triangles, of   */
                                       /* this many inner-node levels, instead of the two levels; 0 = two levels */
 } RtStats;

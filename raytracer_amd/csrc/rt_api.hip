@@ -69,6 +69,7 @@ struct rt_ctx {
     int tlas_depth = 0, max_blas_depth = 0; bool stack_lds_ok = true; // RT_STACK_LDS=0: always the variant with the global overflow (tuning aid)
     // flat tree: scenes of at most RT_FLAT_MAX_INSTANCES instances get ONE tree over all instanced triangles besides the two
     // levels (trace_flat, rt_dev_scene.h); flat_instances = 0: none.  RT_FLAT=0 switches it off (tuning aid, two-level tests).
+    bool stack_deep_ok = true; // RT_STACK_DEEP=0: deep trees always on the spilling stack (tuning aid)
     bool flat_enabled = true, flat_waves8 = true; u32 flat_instances = 0, flat_tris = 0, flat_first1 = 0;
     PackedNode* d_flat_nodes = nullptr; FlatTri* d_flat_tris = nullptr; /* inside the d_flat_nodes allocation */ u32* d_flat_perm = nullptr;
     TreeInfo flat_info = {}; float flat_w2o[RT_FLAT_MAX_INSTANCES][12] = {}; double flat_build_ms = 0;
@@ -249,7 +250,8 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.g = c->g;
     a.ray_sort = c->ray_sort ? 1u : 0u;
     a.wave_major = c->wave_major ? 1u : 0u;
-    a.stack_in_lds = (c->stack_lds_ok && c->tlas_depth + c->max_blas_depth + 2 <= 16) ? 1u : 0u; // rows 0..16 of the per-lane LDS stack (rt_kernels.hip)
+    // rows 0..16 of the per-lane LDS stack of the 6-wave kernels, or rows 0..32 of the 5-wave "deep" kernels (rt_kernels.hip)
+    a.stack_in_lds = !c->stack_lds_ok ? 0u : c->tlas_depth + c->max_blas_depth + 2 <= 16 ? 1u : (c->stack_deep_ok && c->tlas_depth + c->max_blas_depth + 2 <= 32) ? 2u : 0u;
     a.task_counter = c->d_task_counter; a.persistent_slots = c->persistent_slots;
     // persistent traversal waves pay ~2.5 us per 64-ray task and win back the dispatcher's idle slots; since the dispatched
     // kernels run 6 waves per SIMD in wave-major order that no longer pays on any benchmark scene (k_traverse, rt_kernels.hip)
@@ -567,6 +569,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
     if (const char* v = getenv("RT_STACK_LDS")) c->stack_lds_ok = atoi(v) != 0;
     if (const char* v = getenv("RT_FLAT")) c->flat_enabled = atoi(v) != 0;
+    if (const char* v = getenv("RT_STACK_DEEP")) c->stack_deep_ok = atoi(v) != 0;
     if (const char* v = getenv("RT_FLAT_WAVES8")) c->flat_waves8 = atoi(v) != 0;
     if (const char* v = getenv("RT_FRAMES_IN_FLIGHT")) c->frames_in_flight = atoi(v);
     if (const char* v = getenv("RT_EXACT_INSTANCE_BOXES")) c->exact_instance_boxes = atoi(v) != 0;

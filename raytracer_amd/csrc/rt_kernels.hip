@@ -37,8 +37,11 @@ static constexpr u32 SEG_RAD_ZERO = 0x80000000u, SEG_FILL_MASK = 0x7fffffffu;
 // SPILL = false: the host has checked that the trees are shallow enough for the LDS rows alone (sentinel + top-level depth +
 // marker + bottom-level depth + the row above the top <= LDS_STACK_DEPTH + 1, PassArgs::stack_in_lds): no index clamps, no
 // overflow branches -- a fifth of the node step's instructions on the small scenes (everything but the instance field).
-template <bool SPILL>
+// SIDE_REGS: the nine top-level box-test constants wait in registers instead of LDS rows 17-25 while a ray is inside an
+// instance -- the "deep" kernels (k_traverse at 5 waves per SIMD), whose 32 LDS rows all belong to the stack.
+template <bool SPILL, bool SIDE_REGS = false>
 struct LaneStack {
+    float side[SIDE_REGS ? 9 : 1];
     RT_LDS int* lds;
     RT_GLOBAL int* spill;   // &stack_spill[queue slot]
     u32 spill_stride;
@@ -57,8 +60,14 @@ struct LaneStack {
         lds[(i < LDS_STACK_DEPTH ? i : LDS_STACK_DEPTH) * TRAVERSE_WAVE] = v;
         if (i >= LDS_STACK_DEPTH && keep && i < LDS_STACK_DEPTH + OVF_STACK_DEPTH) spill[(size_t) (i - LDS_STACK_DEPTH) * spill_stride] = v;
     }
-    RT_DEV void save_side(const float* v) { for (int k = 0; k < 9; k++) ((RT_LDS float*) lds)[(LDS_SIDE_ROW + k) * TRAVERSE_WAVE] = v[k]; }
-    RT_DEV void load_side(float* v) const { for (int k = 0; k < 9; k++) v[k] = ((const RT_LDS float*) lds)[(LDS_SIDE_ROW + k) * TRAVERSE_WAVE]; }
+    RT_DEV void save_side(const float* v) {
+        if (SIDE_REGS) { for (int k = 0; k < 9; k++) side[SIDE_REGS ? k : 0] = v[k]; return; }
+        for (int k = 0; k < 9; k++) ((RT_LDS float*) lds)[(LDS_SIDE_ROW + k) * TRAVERSE_WAVE] = v[k];
+    }
+    RT_DEV void load_side(float* v) const {
+        if (SIDE_REGS) { for (int k = 0; k < 9; k++) v[k] = side[SIDE_REGS ? k : 0]; return; }
+        for (int k = 0; k < 9; k++) v[k] = ((const RT_LDS float*) lds)[(LDS_SIDE_ROW + k) * TRAVERSE_WAVE];
+    }
     RT_DEV void push(int v) { put(v, true); sp++; }
     RT_DEV int pop() { int v = top(); sp--; return v; }
 };
@@ -297,7 +306,13 @@ static constexpr u32 TASK_PARTS = 64, TASK_STRIDE = 32; // counters 128 bytes ap
 // rt_dev_scene.h); the stack then has all 26 LDS rows to itself (no side store; the host checks the depth).
 template <bool COUNT, int WAVES_PER_SIMD, bool PRIMARY, bool PERSISTENT, bool SPILL, int FLAT = 0>
 __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq, u32 sample_index, u32 n_tasks) {
-    __shared__ int smem[(WAVES_PER_SIMD == 8 ? 20 : 26) * TRAVERSE_WAVE]; // 8 waves per SIMD = 32 per CU: 5 KB each of the 160 KB
+    // DEEP: two-level trees too deep for the 17 stack rows of the 6-wave kernels but not for 33 (sentinel + top-level depth +
+    // marker + bottom-level depth + the row above the top: the 52,743-instance field needs exactly 33): 5 waves per SIMD
+    // by registers, 19 per CU by their 8.25 KB of LDS, all of it stack, the side store in registers (LaneStack SIDE_REGS)
+    // -- the node step without the clamps and overflow branches of the spilling stack (41 instead of 50 vector instructions)
+    constexpr bool DEEP = !PERSISTENT && !SPILL && FLAT == 0 && WAVES_PER_SIMD == 5;
+    __shared__ int smem[(DEEP ? 33 : WAVES_PER_SIMD == 8 ? 20 : 26) * TRAVERSE_WAVE]; // 8 waves per SIMD = 32 per CU: 5 KB each of the 160 KB
+    typedef LaneStack<SPILL, DEEP> Stack;
     TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
     u32 part = blockIdx.x % TASK_PARTS;
     // next task of partition `p`, or n_tasks when it has none left (wave-uniform; costs one atomic round trip)
@@ -361,15 +376,15 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
         }
         if (PERSISTENT) next = (u32) __builtin_amdgcn_readfirstlane((int) next);
         if (active) {
-            LaneStack<SPILL> st; st.lds = (RT_LDS int*) &smem[threadIdx.x]; st.spill = (RT_GLOBAL int*) (a.stack_spill + qi);
+            Stack st; st.lds = (RT_LDS int*) &smem[threadIdx.x]; st.spill = (RT_GLOBAL int*) (a.stack_spill + qi);
             st.spill_stride = a.n_paths; st.sp = 0;
             HitOut best;
             if (FLAT > 0) {
-                trace_flat<(FLAT > 0 ? FLAT : 1), LaneStack<SPILL>, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, best, cnt);
+                trace_flat<(FLAT > 0 ? FLAT : 1), Stack, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, best, cnt);
             } else {
                 TraceState S;
                 trace_begin(a.scene, o, d, a.tmax, S);
-                trace_run<LaneStack<SPILL>, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, S, cnt);
+                trace_run<Stack, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, S, cnt);
                 best = S.best;
             }
             // a miss is its instance field alone (-1): the other four words are neither written nor read (k_shade)
@@ -899,10 +914,12 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
         }
     } else if (primary) {
         if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        else if (a.stack_in_lds == 2u) hipLaunchKernelGGL((k_traverse<false, 5, true, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
         else if (a.stack_in_lds) hipLaunchKernelGGL((k_traverse<false, 6, true, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
         else hipLaunchKernelGGL((k_traverse<false, 6, true, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
     } else {
         if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, false, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        else if (a.stack_in_lds == 2u) hipLaunchKernelGGL((k_traverse<false, 5, false, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
         else if (a.stack_in_lds) hipLaunchKernelGGL((k_traverse<false, 6, false, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
         else hipLaunchKernelGGL((k_traverse<false, 6, false, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
     }
