@@ -380,7 +380,7 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
             st.spill_stride = a.n_paths; st.sp = 0;
             HitOut best;
             if (FLAT > 0) {
-                trace_flat<(FLAT > 0 ? FLAT : 1), Stack, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, best, cnt);
+                trace_flat<(FLAT > 0 ? FLAT : 1), Stack, COUNT, !PRIMARY>(a.scene, o, d, a.tmin, a.tmax, st, best, cnt);
             } else {
                 TraceState S;
                 trace_begin(a.scene, o, d, a.tmax, S);
