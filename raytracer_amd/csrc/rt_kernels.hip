@@ -578,12 +578,12 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
 
 // ---- translucent_chit: sum of bssrdf(|p_i - hit|) * payload_i over all sample points (raytracing.hlsl:321-333) -------
 // One hit per lane, every lane walks all points of its instance in index order (the order of the float sum is part of
-// the result).  The points are staged through LDS in tiles of GATHER_TILE (every lane reads the same point: an LDS
-// broadcast) and the tabulated profile sits in LDS as one float4 per texel, so the two texel fetches of the linear
-// filter are LDS gathers; reading both from global memory had the texture-address unit as the bottleneck
-// (12 divergent loads per pair).  Hits of different translucent instances in one workgroup take turns.
+// the result).  The points are the same for all lanes of a wave and arrive through the scalar cache (k_gather); the
+// tabulated profile sits in LDS as one float4 per texel, so the two texel fetches of the linear filter are LDS gathers --
+// reading both from global memory had the texture-address unit as the bottleneck (12 divergent loads per pair).  Hits
+// of different translucent instances in one workgroup take turns.
 static constexpr int GATHER_BLOCK = 256;
-static constexpr int GATHER_TILE = 512;        // points per tile: 16 KB
+static constexpr int GATHER_TILE = 512;        // points per tile (dipole): 16 KB
 static constexpr int GATHER_TABLE_MAX = 2048;  // texels kept in LDS: 32 KB (raytracing.cpp:113 pads the profile to 2048)
 
 struct alignas(16) GatherPoint { float px, py, pz, pad0, wx, wy, wz, pad1; };
@@ -642,8 +642,8 @@ __global__ __launch_bounds__(SEG) void k_gather_offsets(PassArgs a) {
 // a template parameter so that the unrolled loop body is straight-line code the scheduler can interleave
 template <int MODE>
 __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
-    __shared__ GatherPoint s_pts[GATHER_TILE];
-    __shared__ float4 s_tab[GATHER_TABLE_MAX + 4];
+    __shared__ GatherPoint s_pts[MODE == 0 ? GATHER_TILE : 1];
+    __shared__ float4 s_tab[MODE == 1 ? GATHER_TABLE_MAX + 4 : 1];
     __shared__ int s_next;
     const u32 n_items = a.goff[a.n_segments];
     if (blockIdx.x * GATHER_BLOCK >= n_items) return; // uniform
@@ -687,21 +687,69 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
         __syncthreads();
         cur = s_next;
         if (cur == 0x7fffffff) break; // uniform
-        const TranslucentSlice sl = a.shade.slices[cur];
-        const RtSamplePoint* pts = a.sp_read + sl.offset;
-        const bool mine = my_ti == cur;
-        for (u32 k0 = 0; k0 < sl.count; k0 += GATHER_TILE) {
-            const u32 nk = sl.count - k0 < (u32) GATHER_TILE ? sl.count - k0 : (u32) GATHER_TILE;
-            __syncthreads(); // the previous tile is no longer read
-            for (u32 t = threadIdx.x; t < nk; t += GATHER_BLOCK) {
-                const RtSamplePoint sp = pts[k0 + t];
-                GatherPoint gp;
-                gp.px = sp.position[0]; gp.py = sp.position[1]; gp.pz = sp.position[2]; gp.pad0 = 0.0f;
-                gp.wx = sp.payload[0]; gp.wy = sp.payload[1]; gp.wz = sp.payload[2]; gp.pad1 = 0.0f;
-                s_pts[t] = gp;
+        if (MODE == 0) {
+            // dipole: bound by its transcendental arithmetic, not by LDS -- the points are staged through LDS in tiles (every
+            // lane reads the same point: a broadcast), which keeps them off the scalar cache's miss path
+            const TranslucentSlice sl = a.shade.slices[cur];
+            const RtSamplePoint* pts = a.sp_read + sl.offset;
+            const bool mine = my_ti == cur;
+            for (u32 k0 = 0; k0 < sl.count; k0 += GATHER_TILE) {
+                const u32 nk = sl.count - k0 < (u32) GATHER_TILE ? sl.count - k0 : (u32) GATHER_TILE;
+                __syncthreads(); // the previous tile is no longer read
+                for (u32 t = threadIdx.x; t < nk; t += GATHER_BLOCK) {
+                    const RtSamplePoint sp = pts[k0 + t];
+                    GatherPoint gp;
+                    gp.px = sp.position[0]; gp.py = sp.position[1]; gp.pz = sp.position[2]; gp.pad0 = 0.0f;
+                    gp.wx = sp.payload[0]; gp.wy = sp.payload[1]; gp.wz = sp.payload[2]; gp.pad1 = 0.0f;
+                    s_pts[t] = gp;
+                }
+                __syncthreads();
+                if (!mine) continue;
+                // four points per trip: their sqrt / divide chains are independent and overlap; the sum stays in index order.
+                // `GREY` is a compile-time flag of the loop (two copies): a branch on it between the four terms would keep
+                // the scheduler from interleaving their chains.
+                auto run = [&](auto grey_tag) {
+                    constexpr bool GREY = decltype(grey_tag)::value;
+                    struct Term { f3 bs, w; };
+                    auto term = [&](u32 k) -> Term {
+                        const GatherPoint gp = s_pts[k];
+                        f3 dp = mk3(gp.px, gp.py, gp.pz) - hit;
+                        float radius = MODE != 0 ? sqrt_refined(dot3(dp, dp))
+                                                 : fast_sqrt(__builtin_fmaf(dp.z, dp.z, __builtin_fmaf(dp.y, dp.y, dp.x * dp.x)));
+                        f3 bs;
+                        if (MODE != 0) {
+                            const float coord = div_by_shared(radius, scale, inv_scale);
+                            bs = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, coord)            // :272-276 (the factor is in the LDS texels)
+                                           : fudge_over_z * sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, coord);
+                        } else if (GREY) { float v = dipole_eval_fast(cr, radius); bs = mk3(v, v, v); }               // :278-301
+                        else bs = mk3(dipole_eval_fast(cr, radius), dipole_eval_fast(cg, radius), dipole_eval_fast(cb, radius));
+                        return Term{bs, mk3(gp.wx, gp.wy, gp.wz)};
+                    };
+                    // the sum runs in index order, one fused multiply-add per channel and pair
+                    auto add = [&](const Term& c) {
+                        E.x = __builtin_fmaf(c.bs.x, c.w.x, E.x); E.y = __builtin_fmaf(c.bs.y, c.w.y, E.y); E.z = __builtin_fmaf(c.bs.z, c.w.z, E.z);
+                    };
+                    u32 k = 0;
+                    for (; k + 4 <= nk; k += 4) {
+                        Term c0 = term(k), c1 = term(k + 1), c2 = term(k + 2), c3 = term(k + 3);
+                        add(c0); add(c1); add(c2); add(c3);
+                    }
+                    for (; k < nk; k++) add(term(k));
+                };
+                if (MODE == 0 && grey) run(std::true_type()); else run(std::false_type());
+                pairs += nk;
             }
-            __syncthreads();
-            if (!mine) continue;
+        } else {
+            // The sample points are the same for every lane: they come through the scalar cache (uniform address in the
+            // constant address space: s_load), straight into scalar registers that the vector instructions take as operands
+            // -- no LDS staging, no barriers, and the LDS pipe, which bounded this kernel (two broadcast reads of the point
+            // and two gathers of texels per pair), is left with the texels alone.
+            const int cur_u = __builtin_amdgcn_readfirstlane(cur);
+            const TranslucentSlice sl = a.shade.slices[cur_u];
+            typedef const __attribute__((address_space(4))) float* const_floats;
+            const const_floats pts = (const_floats) (unsigned long long) (a.sp_read + sl.offset); // 6 floats per point (RtSamplePoint)
+            const u32 nk = sl.count;
+            if (my_ti != cur_u) continue;
             // four points per trip: their sqrt / divide chains are independent and overlap; the sum stays in index order.
             // `GREY` is a compile-time flag of the loop (two copies): a branch on it between the four terms would keep
             // the scheduler from interleaving their chains.
@@ -709,8 +757,8 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
                 constexpr bool GREY = decltype(grey_tag)::value;
                 struct Term { f3 bs, w; };
                 auto term = [&](u32 k) -> Term {
-                    const GatherPoint gp = s_pts[k];
-                    f3 dp = mk3(gp.px, gp.py, gp.pz) - hit;
+                    const const_floats q = pts + 6u * k;
+                    f3 dp = mk3(q[0], q[1], q[2]) - hit;
                     float radius = MODE != 0 ? sqrt_refined(dot3(dp, dp))
                                              : fast_sqrt(__builtin_fmaf(dp.z, dp.z, __builtin_fmaf(dp.y, dp.y, dp.x * dp.x)));
                     f3 bs;
@@ -720,7 +768,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
                                        : fudge_over_z * sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, coord);
                     } else if (GREY) { float v = dipole_eval_fast(cr, radius); bs = mk3(v, v, v); }               // :278-301
                     else bs = mk3(dipole_eval_fast(cr, radius), dipole_eval_fast(cg, radius), dipole_eval_fast(cb, radius));
-                    return Term{bs, mk3(gp.wx, gp.wy, gp.wz)};
+                    return Term{bs, mk3(q[3], q[4], q[5])};
                 };
                 // the sum runs in index order, one fused multiply-add per channel and pair
                 auto add = [&](const Term& c) {
