@@ -20,7 +20,8 @@ The JSON line also carries
                 pass of this command, profiles/pmc_traffic.json) / mean launch time (live HIP events on the library's
                 streams); `peak` = 1,024 SIMDs x 2.4 GHz / the cycles a SIMD needs per instruction at best
                 (tools/valu_issue_bench.hip -> profiles/r02_valu_issue.txt: v_fma_f32 / v_mul_f32 with 8 waves per SIMD),
-                so frac <= 1 by construction.  `traffic` / `traffic_frac` are the HBM bytes per launch of the same PMC
+                so frac <= 1 by construction; `frame_issue_frac_at_mix_cost` prices the vector instructions of ALL kernels of
+                a frame at the measured cost of the node step's instruction blend against the frame's wall time (c2 only).  `traffic` / `traffic_frac` are the HBM bytes per launch of the same PMC
                 passes against 8 TB/s; `model` keeps SURVEY.md 8(d)'s bytes-per-ray figure (not an HBM ceiling).
   cpu_baseline: the CPU oracle (oracle/, test infrastructure) timed on this host on a bounded sample of the same
                 workload; it also supplies the per-ray node/triangle/instance counts of the bytes-per-ray model.
@@ -329,6 +330,19 @@ def main():
                 # the hardware's own tally, from the PMC run itself: quad-cycles in which a SIMD executes a vector
                 # instruction over the SIMD quad-cycles of the launch (GRBM_GUI_ACTIVE sums the 8 XCDs)
                 valu_busy = 4.0 * pmc["SQ_ACTIVE_INST_VALU"] / (SIMDS * pmc["GRBM_GUI_ACTIVE"] / 8.0)
+        # the whole frame: vector instructions of ALL its kernels (the same PMC passes; c2 runs each of the five once per frame)
+        # against the issue slots of the frame's wall time, at the measured cost of the node step's blend.  With two frames
+        # in flight the kernels overlap, so this -- not the per-launch figure -- says how full the machine is.
+        frame_insts = frame_issue_frac = None
+        if pmc is not None and args.workload == "c2" and cyc_mix:
+            try:
+                ks = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["c2"]["kernels"]
+                per_frame = ["k_traverse<false, 6, true, false, false, 2>", "k_traverse<false, 6, false, false, false, 2>",
+                             "k_shade<true, true>", "k_shade<false, true>", "k_frame_resolve"]
+                frame_insts = sum(ks[k]["SQ_INSTS_VALU"] for k in per_frame)
+                frame_issue_frac = frame_insts * cyc_mix / (dt_max / args.steps * SIMDS * CLOCK_GHZ * 1e9)
+            except (OSError, KeyError, ValueError):
+                frame_insts = frame_issue_frac = None
         split_label = ("tile split x%d" if tile else "sample-set split x%d") % world
         out = {
             # BASELINE.json's metric; `value` is the whole job: per GPU at N = 1, the sum over the N GPUs otherwise
@@ -354,6 +368,7 @@ def main():
                          # the same instruction rate priced at the measured cost of the node step's instruction blend
                          # (selects, v_fma_mix, min / max run at half the fma rate on gfx950): how full the issue slots are
                          "frac_at_mix_cost": mix_frac, "valu_busy_pmc": valu_busy,
+                         "frame_valu_insts": frame_insts, "frame_issue_frac_at_mix_cost": frame_issue_frac,
                          "mean_launch_ms": mean_launch_ms, "rays_per_launch": rays_per_launch,
                          "traverse_Mrays_s": rays_timed / (stats["traverse_ms"] * 1e-3) / 1e6 if stats["traverse_ms"] > 0 else None,
                          "launches_timed": stats["traverse_launches_timed"], "launches": stats["traverse_launches"],
