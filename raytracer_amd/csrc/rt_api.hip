@@ -475,15 +475,19 @@ int build_flat_tree(rt_ctx* c, const RtInstance* instances, int n, const std::ve
     RT_HIP(hipMalloc(&c->d_flat_nodes, n_nodes * sizeof(PackedNode) + 3 * (size_t) nt * sizeof(FlatTri)));
     c->d_flat_tris = (FlatTri*) (c->d_flat_nodes + n_nodes);
     RT_HIP(hipMalloc(&c->d_flat_perm, 4 * (size_t) nt));
-    BvhNode* d_join = nullptr; Aabb* d_sub = nullptr;
+    BvhNode* d_join = nullptr; // scratch of the build, freed on every way out of the lambda below
     RT_HIP(hipMalloc(&d_join, n_nodes * sizeof(BvhNode) + (RT_FLAT_MAX_INSTANCES + 1) * sizeof(Aabb)));
-    d_sub = (Aabb*) (d_join + n_nodes);
-    RT_HIP(hipEventRecord(c->build_ev[0], c->stream));
-    rc = lbvh_flat_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, src, d_join, d_sub, c->d_flat_perm, c->d_flat_tris, c->d_flat_nodes);
-    if (rc) { (void) hipStreamSynchronize(c->stream); (void) hipFree(d_join); return rc; }
-    RT_HIP(hipEventRecord(c->build_ev[1], c->stream));
-    RT_HIP(hipMemcpyAsync(&c->flat_info, c->lbvh.tree_info, sizeof c->flat_info, hipMemcpyDeviceToHost, c->stream));
-    { hipError_t e = hipStreamSynchronize(c->stream); (void) hipFree(d_join); RT_HIP(e); }
+    auto build = [&]() -> int {
+        Aabb* d_sub = (Aabb*) (d_join + n_nodes);
+        RT_HIP(hipEventRecord(c->build_ev[0], c->stream));
+        int brc = lbvh_flat_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, src, d_join, d_sub, c->d_flat_perm, c->d_flat_tris, c->d_flat_nodes);
+        if (brc) return brc;
+        RT_HIP(hipEventRecord(c->build_ev[1], c->stream));
+        RT_HIP(hipMemcpyAsync(&c->flat_info, c->lbvh.tree_info, sizeof c->flat_info, hipMemcpyDeviceToHost, c->stream));
+        return RT_OK;
+    };
+    rc = build();
+    { hipError_t e = hipStreamSynchronize(c->stream); (void) hipFree(d_join); if (rc) return rc; RT_HIP(e); }
     float ms = 0; RT_HIP(hipEventElapsedTime(&ms, c->build_ev[0], c->build_ev[1]));
     // k_traverse<.., FLAT> keeps the whole stack in its 26 LDS rows: sentinel + one entry per level + the row above the top
     if (c->flat_info.depth + 2 > 26) { free_flat_tree(c); return RT_OK; }
