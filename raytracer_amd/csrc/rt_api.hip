@@ -92,6 +92,7 @@ struct rt_ctx {
     RayQueue q[2]; HitBuf hits; PathState ps; SlotState st[2]; GatherQueue gq; int* d_stack_spill = nullptr;
     u32* d_task_counter = nullptr; u32 persistent_slots = 0; int persistent = 0; // RT_PERSISTENT: 0 never (default), bit 0 queued launches, bit 1 primary launches
     int wave_major = 1; // RT_WAVE_MAJOR
+    int xcd_bands = 1;  // RT_XCD_BANDS
     int ray_sort = 1; // RT_RAY_SORT: group the surviving rays of a bounce by direction octant (fused camera pass)
     u32* d_seg_count = nullptr; u32 n_segments_cap = 0; DeviceStats* d_stats = nullptr;
     // frames in flight: consecutive camera-only dispatches alternate between two lanes (a stream and a set of path buffers
@@ -250,6 +251,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.g = c->g;
     a.ray_sort = c->ray_sort ? 1u : 0u;
     a.wave_major = c->wave_major ? 1u : 0u;
+    a.xcd_bands = c->xcd_bands ? 1u : 0u;
     // rows 0..16 of the per-lane LDS stack of the 6-wave kernels, or rows 0..32 of the 5-wave "deep" kernels (rt_kernels.hip)
     a.stack_in_lds = !c->stack_lds_ok ? 0u : c->tlas_depth + c->max_blas_depth + 2 <= 16 ? 1u : (c->stack_deep_ok && c->tlas_depth + c->max_blas_depth + 2 <= 32) ? 2u : 0u;
     a.task_counter = c->d_task_counter; a.persistent_slots = c->persistent_slots;
@@ -280,6 +282,10 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
         a.scene.flat_bound = c->flat_info.bound;
         a.scene.flat_first1 = c->flat_first1;
         memcpy(a.scene.flat_w2o, c->flat_w2o, sizeof c->flat_w2o);
+        for (u32 i = 0; i < c->flat_instances; i++) { // xform_point43 (rt_dev_math.h) of the camera origin, operation for operation
+            const float* m = c->flat_w2o[i]; const float* p = a.camera_origin;
+            for (int k = 0; k < 3; k++) a.scene.flat_cam_o[i][k] = p[0] * m[k] + p[1] * m[3 + k] + p[2] * m[6 + k] + m[9 + k];
+        }
     }
     a.shade.insts = c->d_inst_shade; a.shade.slot_to_ti = c->d_slot_to_ti; a.shade.slot_count = c->slot_count;
     a.shade.slices = c->d_slices;
@@ -570,6 +576,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_SAH_TRI")) c->sah_tri = (float) atof(v);
     if (const char* v = getenv("RT_RAY_SORT")) c->ray_sort = atoi(v);
     if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
+    if (const char* v = getenv("RT_XCD_BANDS")) c->xcd_bands = atoi(v);
     if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
     if (const char* v = getenv("RT_STACK_LDS")) c->stack_lds_ok = atoi(v) != 0;
     if (const char* v = getenv("RT_FLAT")) c->flat_enabled = atoi(v) != 0;

@@ -90,6 +90,7 @@ struct SceneView {
     u32 flat_first1;         // first triangle of instance 1 (the triangle count when there is one instance)
     float flat_ctr[3], flat_inv_h[3], flat_bound;
     float flat_w2o[RT_FLAT_MAX_INSTANCES][12]; // world_to_object of the instances (InstRec), here so that they arrive as scalars
+    float flat_cam_o[RT_FLAT_MAX_INSTANCES][3]; // the camera origin in the object space of each instance (xform_point43 done by the host: same operations, same result)
 };
 
 struct HitOut {
@@ -244,7 +245,8 @@ RT_DEV void trace_begin(const SceneView& sc, f3 o, f3 d, float tmax, TraceState&
 // BYTE_LINKS: `nodes` is the same for all lanes and inner links are byte offsets (flat tree): the load takes the base as
 // a scalar and the link as its 32-bit offset, no address arithmetic at all.
 template <class Stack, bool COUNT, bool BYTE_LINKS = false>
-RT_DEV int node_step(const RT_GLOBAL PackedNode* nodes, const BoxRay& r, int cur, float tmin, float best_t, Stack& st, TraverseCounters& cnt) {
+RT_DEV int node_step(const RT_GLOBAL PackedNode* nodes, const BoxRay& r, int cur, float tmin, float best_t, Stack& st, TraverseCounters& cnt,
+                     bool* hit0 = nullptr, bool* hit1 = nullptr) {
     // otherwise links to inner nodes count 16-byte units (k_pack_nodes): base + (cur << 4) is one v_lshl_add_u64, whose
     // shift goes up to 4; a node index would need a 64-bit shift and a 64-bit add
     const RT_GLOBAL PackedNode* n = (const RT_GLOBAL PackedNode*) ((const RT_GLOBAL char*) nodes + (BYTE_LINKS ? (unsigned long long) (u32) cur : ((unsigned long long) (u32) cur << 4)));
@@ -262,6 +264,7 @@ RT_DEV int node_step(const RT_GLOBAL PackedNode* nodes, const BoxRay& r, int cur
     // hit iff the padded slab intervals and [tmin, best t] have a common point
     const bool h0 = fmaxf(e0, tmin) <= fminf(x0, best_t);
     const bool h1 = fmaxf(e1, tmin) <= fminf(x1, best_t);
+    if (hit0) { *hit0 = h0; *hit1 = h1; } // which children the ray enters (trace_flat: the root's children are the instances)
     const int c0 = (int) as_u32(q1.z), c1 = (int) as_u32(q1.w);
     const bool both = h0 && h1, any = h0 || h1, first0 = e0 <= e1;
     st.put(first0 ? c1 : c0, both);       // the far child, kept only when both boxes are hit
@@ -337,24 +340,38 @@ RT_DEV RayPrep flat_pick(const FlatPreps<K>& p, u32 inst) {
     r.sx = one ? b.sx : a.sx; r.sy = one ? b.sy : a.sy; r.sz = one ? b.sz : a.sz;
     return r;
 }
-template <int K, class Stack, bool COUNT, bool SPECULATE>
+template <int K, class Stack, bool COUNT, bool SPECULATE, bool CAMERA_ORIGIN = false>
 RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, Stack& st, HitOut& out, TraverseCounters& cnt) {
     static_assert(K >= 1 && K <= RT_FLAT_MAX_INSTANCES && RT_FLAT_MAX_INSTANCES == 2, "flat_pick selects between two preparations");
     ClosestHit best; best.t = tmax; best.u_num = 0.0f; best.v_num = 0.0f; best.det = 1.0f; best.inst = -1; best.tri = -1; best.prim_global = 0;
     const float big = 3.0e38f; // NaN or infinite rays miss without a walk (trace_begin)
     const bool finite = fabsf(o.x) <= big && fabsf(o.y) <= big && fabsf(o.z) <= big && fabsf(d.x) <= big && fabsf(d.y) <= big && fabsf(d.z) <= big;
     const BoxRay br = make_box_ray(o, d, sc.flat_bound, mk3(sc.flat_ctr[0], sc.flat_ctr[1], sc.flat_ctr[2]), mk3(sc.flat_inv_h[0], sc.flat_inv_h[1], sc.flat_inv_h[2]));
-    FlatPreps<K> preps;
-    for (int i = 0; i < K; i++) {
-        preps.rp[i] = prepare_ray(xform_point43(sc.flat_w2o[i], o), xform_dir43(sc.flat_w2o[i], d)); // the matrices are kernel arguments: scalar loads
-#if defined(__HIP_DEVICE_COMPILE__)
-        // computed here, once per ray: left alone the compiler keeps d[kz] instead of 1 / d[kz] and divides again at every leaf
-        asm volatile("" : "+v"(preps.rp[i].sx), "+v"(preps.rp[i].sy), "+v"(preps.rp[i].sz));
-#endif
-    }
     st.reset();
     int cur = finite ? 0 : RT_TRAVERSAL_DONE;
     const RT_GLOBAL PackedNode* nodes = (const RT_GLOBAL PackedNode*) sc.flat_nodes;
+    // Two instances: node 0 joins their subtrees (lbvh_flat_build: child i = instance i), so the first step of the walk, taken
+    // here, says which instances a ray can reach at all, and the wave prepares the ray (transform, shear with three divisions:
+    // ~95 vector instructions each) only for the instances that one of its rays enters -- a wave of sky or floor pixels skips
+    // one or both.  The step is the one the loop would have taken first: same stack, same order, same counters.
+    bool enters[2] = { true, true };
+    if (K > 1) {
+        enters[0] = false; enters[1] = false;
+        if (cur >= 0) cur = node_step<Stack, COUNT, true>(nodes, br, cur, tmin, best.t, st, cnt, &enters[0], &enters[1]);
+    }
+    FlatPreps<K> preps;
+    for (int i = 0; i < K; i++) {
+        RayPrep& rp = preps.rp[i];
+        rp.o = mk3(0.0f, 0.0f, 0.0f); rp.kz = 0; rp.flip = 0u; rp.sx = 0.0f; rp.sy = 0.0f; rp.sz = 0.0f;
+        if (K > 1 && !__any(enters[i])) continue; // wave-uniform
+        // the matrices are kernel arguments (scalar loads); CAMERA_ORIGIN: o is the camera's for every lane and the host has transformed it
+        const f3 oo = CAMERA_ORIGIN ? mk3(sc.flat_cam_o[i][0], sc.flat_cam_o[i][1], sc.flat_cam_o[i][2]) : xform_point43(sc.flat_w2o[i], o);
+        rp = prepare_ray(oo, xform_dir43(sc.flat_w2o[i], d));
+#if defined(__HIP_DEVICE_COMPILE__)
+        // computed here, once per ray: left alone the compiler keeps d[kz] instead of 1 / d[kz] and divides again at every leaf
+        asm volatile("" : "+v"(rp.sx), "+v"(rp.sy), "+v"(rp.sz));
+#endif
+    }
     int pending = RT_TRAVERSAL_DONE; // a leaf put aside (RT_TRAVERSAL_DONE: none)
     for (;;) {
         int leaf;

@@ -341,6 +341,12 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
         return n_tasks;
     };
     u32 task = blockIdx.x; // = the wave of 64 consecutive queue slots (or pixels of a tile) this wave works on
+    // XCD tiles: one-wave workgroups are dealt to the 8 XCDs round-robin (b and b + 8 share an L2), so in launch order the 16
+    // waves of a tile would run on all 8 XCDs and every L2 would hold what the tile touches.  Workgroup 128 g + 8 w + x
+    // takes wave w of tile 8 g + x instead: a tile stays on one XCD, the tiles go round the XCDs (bands of the image per XCD
+    // were measured too: -25 %, the bands cost different amounts).  Queued launches in wave-major order have this by
+    // themselves when the number of segments is a multiple of 8.
+    if (!PERSISTENT && PRIMARY && a.xcd_bands && (task >> 7) < (n_tasks >> 7)) task = (((task >> 7) << 3) + (task & 7u)) * 16u + ((task >> 3) & 15u);
 
     if (PERSISTENT) { task = take(part); if (task >= n_tasks) task = steal(); }
     while (task < n_tasks) {
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
             st.spill_stride = a.n_paths; st.sp = 0;
             HitOut best;
             if (FLAT > 0) {
-                trace_flat<(FLAT > 0 ? FLAT : 1), Stack, COUNT, !PRIMARY>(a.scene, o, d, a.tmin, a.tmax, st, best, cnt);
+                trace_flat<(FLAT > 0 ? FLAT : 1), Stack, COUNT, !PRIMARY, PRIMARY>(a.scene, o, d, a.tmin, a.tmax, st, best, cnt);
             } else {
                 TraceState S;
                 trace_begin(a.scene, o, d, a.tmax, S);
