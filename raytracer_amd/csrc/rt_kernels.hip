@@ -86,14 +86,33 @@ RT_DEV u32 block_rank(bool pred, u32* s_wave /* [16] */, u32& total) {
 }
 
 // the same with a 3-bit key: threads with pred set are ranked by (key, thread index).  s_cnt: [8 * 16 + 1] words.
+// Three ballots (one per key bit) give the lane masks of all eight keys as scalar expressions: their sizes go to LDS through
+// one 8-lane store, and a lane's own mask is bp & ~((b0 ^ k0) | (b1 ^ k1) | (b2 ^ k2)), k_i = all ones where its key bit is set -- ~35 vector instructions per wave
+// where a ballot per key took 94; a wave without any such thread (the waves behind the fill of a compacted segment: half
+// of all waves in the later bounces) only stores its eight zeros.
 RT_DEV u32 block_rank_keyed(bool pred, u32 key, u32* s_cnt, u32& total) {
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     __syncthreads(); // s_cnt may still be read from a previous call
-    unsigned long long mine = 0;
-    for (u32 k = 0; k < 8u; k++) {
-        const unsigned long long m = __ballot(pred && key == k);
-        if (lane == 0) s_cnt[k * 16u + wave] = (u32) __popcll(m);
-        if (key == k) mine = m;
+    const unsigned long long bp = __ballot(pred);
+    u32 below = 0; // threads of this wave with pred, the same key and a lower lane
+    if (bp == 0ull) { // wave-uniform
+        if (lane < 8u) s_cnt[lane * 16u + wave] = 0u;
+    } else {
+        const unsigned long long b0 = __ballot((key & 1u) != 0u), b1 = __ballot((key & 2u) != 0u), b2 = __ballot((key & 4u) != 0u);
+        int counts = 0;
+#pragma unroll
+        for (u32 k = 0; k < 8u; k++) { // scalar work: mask and size of key k
+            const unsigned long long m = bp & ((k & 1u) ? b0 : ~b0) & ((k & 2u) ? b1 : ~b1) & ((k & 4u) ? b2 : ~b2);
+            const int c = __popcll(m); (void) c;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(counts) : "s"(c), "n"(k)); // lane k of `counts` = c (a vector register written through a scalar operand: no store to memory)
+#endif
+        }
+        if (lane < 8u) s_cnt[lane * 16u + wave] = (u32) counts;
+        const u32 k0 = 0u - (key & 1u), k1 = 0u - ((key >> 1) & 1u), k2 = 0u - ((key >> 2) & 1u); // all ones where the key bit is set
+        const u32 lo = (u32) bp & ~((((u32) b0) ^ k0) | (((u32) b1) ^ k1) | (((u32) b2) ^ k2));
+        const u32 hi = (u32) (bp >> 32) & ~((((u32) (b0 >> 32)) ^ k0) | (((u32) (b1 >> 32)) ^ k1) | (((u32) (b2 >> 32)) ^ k2));
+        below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
     }
     __syncthreads();
     if (wave == 0) { // exclusive scan of the 128 (key, wave) counts in key-major order: two per lane
@@ -106,7 +125,7 @@ RT_DEV u32 block_rank_keyed(bool pred, u32 key, u32* s_cnt, u32& total) {
     }
     __syncthreads();
     total = s_cnt[128];
-    return s_cnt[key * 16u + wave] + (u32) __popcll(mine & ((1ull << lane) - 1ull));
+    return s_cnt[key * 16u + wave] + below;
 }
 
 RT_DEV u32 wave_sum(u32 v) {
