@@ -412,9 +412,17 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
                 trace_run<Stack, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, S, cnt);
                 best = S.best;
             }
-            // a miss is its instance field alone (-1): the other four words are neither written nor read (k_shade)
-            a.hits.inst[qi] = best.inst;
-            if (best.inst >= 0) { a.hits.t[qi] = best.t; a.hits.u[qi] = best.u; a.hits.v[qi] = best.v; a.hits.tri[qi] = best.tri; }
+            // one 16-byte record per slot (t, u, v, id) in the space of the t, u, v and inst arrays, which are consecutive in
+            // the arena (carve_path_buffers): one store here and one load in k_shade instead of five each.  Scenes with a flat
+            // tree (whichever walk runs: the persistent kernels take the two levels) pack the instance into bit 30 of the id --
+            // RT_FLAT_MAX_INSTANCES is 2 and their triangles number < 2^20; otherwise id = instance and the triangle goes to its
+            // own array.  A miss is id = -1; the other words are then not read.
+            static_assert(RT_FLAT_MAX_INSTANCES <= 2 && RT_FLAT_MAX_TRIS <= (1u << 30), "hit id packing");
+            const bool packed = FLAT > 0 || a.scene.flat_instances != 0u; // uniform
+            int id = best.inst;
+            if (packed) id = best.inst < 0 ? -1 : (best.inst << 30) | best.tri;
+            ((float4*) a.hits.t)[qi] = make_float4(best.t, best.u, best.v, __int_as_float(id));
+            if (!packed && best.inst >= 0) a.hits.tri[qi] = best.tri;
         }
         if (!PERSISTENT) break;
         task = next * TASK_PARTS + part < n_tasks ? next * TASK_PARTS + part : n_tasks;
@@ -483,8 +491,13 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
     }
     if (active) {
         HitOut h;
-        h.inst = a.hits.inst[qi]; h.t = inf_f32(); h.u = 0.0f; h.v = 0.0f; h.tri = -1;
-        if (h.inst >= 0) { h.t = a.hits.t[qi]; h.u = a.hits.u[qi]; h.v = a.hits.v[qi]; h.tri = a.hits.tri[qi]; }
+        const float4 rec = ((const float4*) a.hits.t)[qi]; // (t, u, v, id) as k_traverse wrote it
+        h.inst = __float_as_int(rec.w); h.t = inf_f32(); h.u = 0.0f; h.v = 0.0f; h.tri = -1;
+        if (h.inst >= 0) {
+            h.t = rec.x; h.u = rec.y; h.v = rec.z;
+            if (a.scene.flat_instances) { h.tri = h.inst & 0x3fffffff; h.inst = h.inst >> 30; } // uniform
+            else h.tri = a.hits.tri[qi];
+        }
         h.prim_global = 0;
         float payload_t = a.probe ? inf_f32() : (float) bounce; // raytracing.hlsl:102-107
         shade_ray(a.shade, a.g, a.fudge, o, d, h, payload_t, rng, r, tail);
