@@ -71,6 +71,8 @@ struct rt_ctx {
     // levels (trace_flat, rt_dev_scene.h); flat_instances = 0: none.  RT_FLAT=0 switches it off (tuning aid, two-level tests).
     bool stack_deep_ok = true; // RT_STACK_DEEP=0: deep trees always on the spilling stack (tuning aid)
     bool flat_enabled = true, flat_waves8 = true; u32 flat_instances = 0, flat_tris = 0, flat_first1 = 0;
+    // inlined instance of the two-level walk (SceneView::inl_inst); RT_INLINE=0 switches it off (tuning aid)
+    bool inline_enabled = true; int inl_inst = -1; u32 inl_count = 0; const TriRec* inl_tris = nullptr; u32 inl_copy_bytes = 0; float inl_w2o[12] = {};
     PackedNode* d_flat_nodes = nullptr; FlatTri* d_flat_tris = nullptr; /* inside the d_flat_nodes allocation */ u32* d_flat_perm = nullptr;
     TreeInfo flat_info = {}; float flat_w2o[RT_FLAT_MAX_INSTANCES][12] = {}; double flat_build_ms = 0;
     // translucent sample points, all instances concatenated
@@ -274,6 +276,8 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.scene.tlas_nodes = c->d_tlas_nodes; a.scene.insts = c->d_inst_rec;
     for (int k = 0; k < 3; k++) { a.scene.tlas_ctr[k] = c->tlas_info.ctr[k]; a.scene.tlas_inv_h[k] = c->tlas_info.inv_h[k]; }
     a.scene.tlas_bound = c->tlas_info.bound;
+    a.scene.inl_inst = c->inl_inst; a.scene.inl_count = c->inl_count; a.scene.n_insts = c->n_instances; a.scene.inl_tris = c->inl_tris; a.scene.inl_copy_bytes = c->inl_copy_bytes;
+    memcpy(a.scene.inl_w2o, c->inl_w2o, sizeof c->inl_w2o);
     a.scene.flat_instances = c->flat_instances;
     a.flat_waves8 = (c->flat_waves8 && c->flat_instances == 1 && c->flat_info.depth + 2 <= 20) ? 1u : 0u;
     if (c->flat_instances) {
@@ -577,6 +581,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_RAY_SORT")) c->ray_sort = atoi(v);
     if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
     if (const char* v = getenv("RT_XCD_BANDS")) c->xcd_bands = atoi(v);
+    if (const char* v = getenv("RT_INLINE")) c->inline_enabled = atoi(v) != 0;
     if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
     if (const char* v = getenv("RT_STACK_LDS")) c->stack_lds_ok = atoi(v) != 0;
     if (const char* v = getenv("RT_FLAT")) c->flat_enabled = atoi(v) != 0;
@@ -801,18 +806,40 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
     dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
     free_flat_tree(c);
     c->n_instances = 0; c->tlas_depth = 0; // no top level until this call has succeeded: a failure below leaves rt_dispatch_rays answering RT_ERR_STATE
-    u32 n_nodes = n > 1 ? (u32) n - 1 : 1;
+    // the instance to inline (SceneView::inl_inst): among those of at most RT_INLINE_MAX_TRIS triangles the one that reaches
+    // furthest (a floor under 50,000 meshes, a room around them); scenes that get a flat tree have no use for it
+    c->inl_inst = -1; c->inl_count = 0; c->inl_tris = nullptr; c->inl_copy_bytes = 0;
+    u32 inl_k = 0;
+    if (c->inline_enabled && n > RT_FLAT_MAX_INSTANCES) {
+        float reach_best = 0.0f;
+        for (int i = 0; i < n; i++) {
+            const Blas& b = c->blas[instances[i].blas];
+            if (b.n_tris == 0 || b.n_tris > RT_INLINE_MAX_TRIS) continue;
+            const float* m = instances[i].transform;
+            float reach = 0.0f;
+            for (int k = 0; k < 3; k++) reach = std::max(reach, fabsf(m[12 + k]) + b.info.bound * (fabsf(m[k]) + fabsf(m[4 + k]) + fabsf(m[8 + k])));
+            if (c->inl_inst < 0 || reach > reach_best) { c->inl_inst = i; reach_best = reach; inl_k = b.n_tris; }
+        }
+    }
+    const u32 n_prims = (u32) n - (inl_k ? 1u : 0u); // top-level primitives: the instances but the inlined one
+    u32 n_nodes = n_prims > 1 ? n_prims - 1 : 1;
     RT_HIP(hipMalloc(&c->d_inst_rec, sizeof(InstRec) * n));
     RT_HIP(hipMalloc(&c->d_inst_shade, sizeof(InstShade) * n));
     RT_HIP(hipMalloc(&c->d_tlas_nodes, sizeof(PackedNode) * n_nodes));
-    RT_HIP(hipMalloc(&c->d_tlas_perm, 4 * (size_t) n));
+    RT_HIP(hipMalloc(&c->d_tlas_perm, 4 * (size_t) n_prims));
     RT_HIP(hipMemcpyAsync(c->d_inst_rec, rec.data(), sizeof(InstRec) * n, hipMemcpyHostToDevice, c->stream));
     RT_HIP(hipMemcpyAsync(c->d_inst_shade, shade.data(), sizeof(InstShade) * n, hipMemcpyHostToDevice, c->stream));
-    int rc = lbvh_workspace_reserve(c->lbvh, (u32) n); if (rc) return rc;
+    int rc = lbvh_workspace_reserve(c->lbvh, n_prims); if (rc) return rc;
     RT_HIP(hipEventRecord(c->build_ev[0], c->stream));
     const bool exact_boxes = c->exact_instance_boxes && vertex_work <= (4ull << 30);
     rc = lbvh_instance_boxes(c->stream, c->lbvh, c->d_inst_shade, c->d_inst_rec, (u32) n, exact_boxes); if (rc) return rc;
-    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, (u32) n, 1, true, c->d_tlas_nodes, c->d_tlas_perm); if (rc) return rc;
+    if (c->inl_inst >= 0) {
+        const Blas& b = c->blas[instances[c->inl_inst].blas];
+        if (c->inl_inst != n - 1) { rc = lbvh_move_box(c->stream, c->lbvh, (u32) c->inl_inst, (u32) n - 1u); if (rc) { c->inl_inst = -1; return rc; } }
+        c->inl_count = inl_k; c->inl_tris = b.d_tris; c->inl_copy_bytes = (u32) (b.n_tris * sizeof(TriRec));
+        memcpy(c->inl_w2o, rec[c->inl_inst].world_to_object, 48);
+    }
+    rc = lbvh_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, n_prims, 1, true, c->d_tlas_nodes, c->d_tlas_perm); if (rc) { c->inl_inst = -1; return rc; }
     RT_HIP(hipEventRecord(c->build_ev[1], c->stream));
     RT_HIP(hipMemcpyAsync(&c->tlas_info, c->lbvh.tree_info, sizeof c->tlas_info, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));

@@ -371,6 +371,14 @@ int lbvh_triangle_boxes(hipStream_t s, LbvhWorkspace& w, const RtVertex* verts, 
     return RT_OK;
 }
 
+__global__ void k_move_box(Aabb* __restrict__ boxes, u32 dst, u32 src) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) boxes[dst] = boxes[src];
+}
+int lbvh_move_box(hipStream_t s, LbvhWorkspace& w, u32 dst, u32 src) {
+    hipLaunchKernelGGL(k_move_box, dim3(1), dim3(64), 0, s, w.boxes, dst, src);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
 int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const InstShade* shade, const InstRec* insts, u32 n, bool exact) {
     if (n == 0) return RT_OK;
     if (exact) hipLaunchKernelGGL(k_instance_boxes_exact, dim3(n), dim3(64), 0, s, shade, n, w.boxes);

@@ -78,10 +78,24 @@ struct alignas(16) FlatTri {
 #define RT_FLAT_MAX_INSTANCES 2
 #define RT_FLAT_MAX_TRIS (1u << 20) // triangles of all instances together (leaf links keep 24 bits for the first one)
 
+#define RT_INLINE_MAX_TRIS 8
 struct SceneView {
     const PackedNode* tlas_nodes;
     const InstRec* insts;
     float tlas_ctr[3], tlas_inv_h[3], tlas_bound;
+    // Inlined instance (inl_inst < 0: none): one instance of at most RT_INLINE_MAX_TRIS triangles -- a floor with a luminaire,
+    // the walls of a room: a few large triangles whose instance box holds the whole scene, so that every ray would enter it
+    // (and, its origin being inside, enter it first) -- is not in the top level at all: every ray tests its triangles
+    // before the walk, all lanes together, in the instance's object space like any other triangle test (trace_begin).  The
+    // walk then starts with that hit's t as its bound, as it did when the instance came first, and the top level holds the
+    // other n_insts - 1 instances: its primitive p is instance p, except p == inl_inst, which is the last instance
+    // (rt_build_tlas moves the last box into the free slot).
+    int inl_inst;
+    u32 inl_count;           // triangles of the inlined instance
+    u32 n_insts;
+    const TriRec* inl_tris;  // its TriRec array (three copies of inl_copy_bytes)
+    u32 inl_copy_bytes;
+    float inl_w2o[12];
     // flat tree (flat_instances = 0: none, traverse the two levels)
     const PackedNode* flat_nodes;
     const FlatTri* flat_tris;
@@ -285,6 +299,16 @@ template <class Stack, bool COUNT>
 RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, Stack& st, TraceState& S, TraverseCounters& cnt) {
     st.reset();
     { const BoxRay& b = S.br; const float v[9] = { b.idx, b.idy, b.idz, b.cnx, b.cny, b.cnz, b.cfx, b.cfy, b.cfz }; st.save_side(v); }
+    if (sc.inl_inst >= 0 && S.cur != RT_TRAVERSAL_DONE) { // the triangles of the inlined instance first (SceneView::inl_inst); uniform but for NaN rays
+        const RayPrep irp = prepare_ray(xform_point43(sc.inl_w2o, o), xform_dir43(sc.inl_w2o, d));
+        const RT_GLOBAL TriRec* tr = (const RT_GLOBAL TriRec*) ((const RT_GLOBAL char*) sc.inl_tris + (size_t) ((u32) irp.kz * sc.inl_copy_bytes));
+        for (u32 j = 0; j < sc.inl_count; j++) {
+            Quad a = ldq(tr + j, 0), b = ldq(tr + j, 1), c = ldq(tr + j, 2);
+            if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
+            triangle_candidate(irp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), tmin, sc.inl_inst, (int) j, as_u32(c.y), S.ch);
+        }
+        if (sc.n_insts < 2u) S.cur = RT_TRAVERSAL_DONE; // nothing else in the scene (cannot happen: such scenes get a flat tree)
+    }
     for (;;) {
         // ---- inner nodes ---------------------------------------------------------------------------------------
         while (S.cur >= 0) S.cur = node_step<Stack, COUNT>(S.nodes, S.br, S.cur, tmin, S.ch.t, st, cnt);
@@ -295,7 +319,8 @@ RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, S
             S.cur = st.pop();
         } else if (!S.bottom) {
             // ---- TLAS leaf: enter the instance ---------------------------------------------------------------------
-            S.cur_inst = ~S.cur;
+            const int p = ~S.cur;
+            S.cur_inst = p == sc.inl_inst ? (int) sc.n_insts - 1 : p; // the slot of the inlined instance holds the last one (SceneView)
             if (COUNT) { cnt.insts++; if (first_active_lane()) cnt.inst_trips++; }
             trace_bottom_level(sc, o, d, S);
             st.push(RT_STACK_MARKER);

@@ -79,6 +79,8 @@ int lbvh_triangle_boxes(hipStream_t s, LbvhWorkspace& w, const RtVertex* verts, 
 // world boxes of n instances (8 corners of each BLAS root box through object_to_world, padded) -> w.boxes
 // exact: boxes from every vertex of the instance's BLAS (tighter); otherwise from the corners of its object-space box
 int lbvh_instance_boxes(hipStream_t s, LbvhWorkspace& w, const rtd::InstShade* shade, const rtd::InstRec* insts, u32 n, bool exact);
+// w.boxes[dst] = w.boxes[src] (rt_build_tlas: the last instance's box takes the slot of the inlined instance, SceneView::inl_inst)
+int lbvh_move_box(hipStream_t s, LbvhWorkspace& w, u32 dst, u32 src);
 // builds the hierarchy over w.boxes[0..n); nodes_out has max(1, n-1) entries; perm_out[n] = sorted -> original.
 // builder: 0 = Karras LBVH hierarchy, 1 = PLOC agglomerative clustering (pw required), 2 = top-down binned SAH for
 // up to SAH_BUILD_MAX primitives (sw required; larger inputs fall back to PLOC), 3 = SAH for bottom-level trees and

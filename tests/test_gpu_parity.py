@@ -179,3 +179,23 @@ def test_top_level_rebuilds_switch_between_the_flat_tree_and_the_two_levels(orac
             pu.compare_images(gpu.read_accumulator(), cpu.read_accumulator())
     finally:
         gpu.close(); cpu.close()
+
+
+@pytest.mark.parametrize("inline", ["0", "1"])
+def test_inlined_instance_and_plain_two_levels_agree_with_the_oracle(oracle_mod, monkeypatch, inline):
+    """scenes of more than two instances keep the two levels; the small instance that reaches furthest (at most 8
+    triangles: the floor with its luminaire) is then tested by every ray before the walk instead of sitting in the top
+    level (RT_INLINE=1, the default: rt_dev_scene.h SceneView::inl_inst) -- same hits, bit for bit, as with every instance
+    in the top level (RT_INLINE=0).  Covers the inlined instance last in the array (the field), first and in the middle
+    (the top level then holds the last instance in its slot), and two candidates of which one is taken."""
+    from raytracer_amd import host
+    monkeypatch.setenv("RT_INLINE", inline)               # read at rt_create
+    _check_scene(scenes.bunny_field(128, 72, spp=1, bounces=2, grid=8, count=50), oracle_mod, brute_force=False)
+    s = scenes.bunny(96, 54, spp=1, bounces=3)            # [bunny, floor quad]
+    cube = scenes.debug_cube(8, 8).blas[0]
+    s.blas.append(cube)
+    s.instances = [s.instances[1], s.instances[0], (host.affine_transform(0.3, 1.0, (0.7, -0.5, 0.2)), 2)]   # floor first
+    _check_scene(s, oracle_mod, frames=2)
+    s.instances = [s.instances[1], s.instances[0], s.instances[2],
+                   (host.affine_transform(0.05, 0.3, (-0.6, 0.4, 0.4)), 1)]                              # floor in the middle + a small copy of it
+    _check_scene(s, oracle_mod)
