@@ -85,46 +85,58 @@ RT_DEV u32 block_rank(bool pred, u32* s_wave /* [16] */, u32& total) {
     return rank;
 }
 
-// the same with a 3-bit key: threads with pred set are ranked by (key, thread index).  s_cnt: [8 * 16 + 1] words.
-// Three ballots (one per key bit) give the lane masks of all eight keys as scalar expressions: their sizes go to LDS through
-// one 8-lane store, and a lane's own mask is bp & ~((b0 ^ k0) | (b1 ^ k1) | (b2 ^ k2)), k_i = all ones where its key bit is set -- ~35 vector instructions per wave
-// where a ballot per key took 94; a wave without any such thread (the waves behind the fill of a compacted segment: half
-// of all waves in the later bounces) only stores its eight zeros.
+// the same with a BITS-bit key: threads with pred set are ranked by (key, thread index).  s_cnt: [(16 << BITS) + 1] words.
+// One ballot per key bit gives the lane masks of all keys as scalar expressions: their sizes go to LDS through one store
+// of the first 2^BITS lanes, and a lane's own mask is bp & ~((b0 ^ k0) | (b1 ^ k1) | ...), k_i = all ones where its key bit
+// is set -- ~35 vector instructions per wave for 8 keys, where a ballot per key took 94; a wave without any such thread (the
+// waves behind the fill of a compacted segment: half of all waves in the later bounces) only stores its zeros.
+template <int BITS>
 RT_DEV u32 block_rank_keyed(bool pred, u32 key, u32* s_cnt, u32& total) {
+    constexpr u32 NK = 1u << BITS, PER = NK * 16u / 64u; // keys; (key, wave) counts per lane of the scan
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     __syncthreads(); // s_cnt may still be read from a previous call
     const unsigned long long bp = __ballot(pred);
     u32 below = 0; // threads of this wave with pred, the same key and a lower lane
     if (bp == 0ull) { // wave-uniform
-        if (lane < 8u) s_cnt[lane * 16u + wave] = 0u;
+        if (lane < NK) s_cnt[lane * 16u + wave] = 0u;
     } else {
-        const unsigned long long b0 = __ballot((key & 1u) != 0u), b1 = __ballot((key & 2u) != 0u), b2 = __ballot((key & 4u) != 0u);
+        unsigned long long b[BITS];
+#pragma unroll
+        for (int i = 0; i < BITS; i++) b[i] = __ballot(((key >> i) & 1u) != 0u);
         int counts = 0;
 #pragma unroll
-        for (u32 k = 0; k < 8u; k++) { // scalar work: mask and size of key k
-            const unsigned long long m = bp & ((k & 1u) ? b0 : ~b0) & ((k & 2u) ? b1 : ~b1) & ((k & 4u) ? b2 : ~b2);
+        for (u32 k = 0; k < NK; k++) { // scalar work: mask and size of key k
+            unsigned long long m = bp;
+#pragma unroll
+            for (int i = 0; i < BITS; i++) m &= ((k >> i) & 1u) ? b[i] : ~b[i];
             const int c = __popcll(m); (void) c;
 #if defined(__HIP_DEVICE_COMPILE__)
             asm("v_writelane_b32 %0, %1, %2" : "+v"(counts) : "s"(c), "n"(k)); // lane k of `counts` = c (a vector register written through a scalar operand: no store to memory)
 #endif
         }
-        if (lane < 8u) s_cnt[lane * 16u + wave] = (u32) counts;
-        const u32 k0 = 0u - (key & 1u), k1 = 0u - ((key >> 1) & 1u), k2 = 0u - ((key >> 2) & 1u); // all ones where the key bit is set
-        const u32 lo = (u32) bp & ~((((u32) b0) ^ k0) | (((u32) b1) ^ k1) | (((u32) b2) ^ k2));
-        const u32 hi = (u32) (bp >> 32) & ~((((u32) (b0 >> 32)) ^ k0) | (((u32) (b1 >> 32)) ^ k1) | (((u32) (b2 >> 32)) ^ k2));
-        below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+        if (lane < NK) s_cnt[lane * 16u + wave] = (u32) counts;
+        u32 other_lo = 0u, other_hi = 0u; // lanes whose key differs from this lane's in some bit
+#pragma unroll
+        for (int i = 0; i < BITS; i++) {
+            const u32 ki = 0u - ((key >> i) & 1u); // all ones where the key bit is set
+            other_lo |= (u32) b[i] ^ ki; other_hi |= (u32) (b[i] >> 32) ^ ki;
+        }
+        below = __builtin_amdgcn_mbcnt_hi((u32) (bp >> 32) & ~other_hi, __builtin_amdgcn_mbcnt_lo((u32) bp & ~other_lo, 0u));
     }
     __syncthreads();
-    if (wave == 0) { // exclusive scan of the 128 (key, wave) counts in key-major order: two per lane
-        const u32 c0 = s_cnt[2u * lane], c1 = s_cnt[2u * lane + 1u];
-        u32 inc = c0 + c1;
+    if (wave == 0) { // exclusive scan of the (key, wave) counts in key-major order: PER per lane
+        u32 c[PER], sum = 0;
+#pragma unroll
+        for (u32 k = 0; k < PER; k++) { c[k] = s_cnt[PER * lane + k]; sum += c[k]; }
+        u32 inc = sum;
         for (int off = 1; off < 64; off <<= 1) { u32 o = __shfl_up(inc, off); if ((int) lane >= off) inc += o; }
-        const u32 base = inc - (c0 + c1);
-        s_cnt[2u * lane] = base; s_cnt[2u * lane + 1u] = base + c0;
-        if (lane == 63u) s_cnt[128] = inc;
+        u32 run = inc - sum;
+#pragma unroll
+        for (u32 k = 0; k < PER; k++) { s_cnt[PER * lane + k] = run; run += c[k]; }
+        if (lane == 63u) s_cnt[NK * 16u] = inc;
     }
     __syncthreads();
-    total = s_cnt[128];
+    total = s_cnt[NK * 16u];
     return s_cnt[key * 16u + wave] + below;
 }
 
@@ -558,18 +570,35 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         if (threadIdx.x == 0) a.seg_count[inq ^ 1u][blockIdx.x] = 0u;
         return;
     }
+    __shared__ u32 s_cnt[257];
+    // rank of a surviving path in the next queue: by (key, thread) when a.ray_sort is set, by thread otherwise
+    auto rank_sorted = [&]() -> u32 {
+        if (!a.ray_sort || (!FUSED && !a.sort_box_on)) return block_rank(cont, s_wave, total); // (the octant sort alone does not pay for the scattered stores of the unfused pass: cornell as shipped -2.7 %)
+        const u32 key = (nd.x < 0.0f ? 1u : 0u) | (nd.y < 0.0f ? 2u : 0u) | (nd.z < 0.0f ? 4u : 0u);
+        if (!a.sort_box_on) return block_rank_keyed<3>(cont, key, s_cnt, total);
+        // Two-instance scenes (a mesh in a room, a mesh on a floor): whether the new ray crosses the world box of the instance
+        // with the most triangles is a second sort key.  A wave takes as long as its longest ray, and the rays that go for
+        // the mesh are the long ones: apart, they leave the other waves short.  (uniform branch)
+        const float ix = fast_rcp(nd.x), iy = fast_rcp(nd.y), iz = fast_rcp(nd.z);
+        const float x0 = (a.sort_box[0] - no.x) * ix, x1 = (a.sort_box[3] - no.x) * ix;
+        const float y0 = (a.sort_box[1] - no.y) * iy, y1 = (a.sort_box[4] - no.y) * iy;
+        const float z0 = (a.sort_box[2] - no.z) * iz, z1 = (a.sort_box[5] - no.z) * iz;
+        const float en = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+        const float ex = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const u32 cross = en <= ex ? 1u : 0u;
+        // measured (profiles/r02_ab_sort_box.txt): the fused pass keeps the octants and queues the crossing rays last (C2 +2 %,
+        // first: +1.2 %); the unfused pass, whose seven stores per ray scatter with the key, does best with this one bit alone,
+        // crossing rays first (C4 +8.7 %; last: +5.5 %; with the octants: +3.6 %)
+        if (!FUSED) return block_rank_keyed<3>(cont, cross ^ 1u, s_cnt, total);
+        return block_rank_keyed<4>(cont, key | (cross << 3), s_cnt, total);
+    };
     if (FUSED) {
         // Survivors are compacted to the front of the segment, grouped by the octant of their new direction when
         // a.ray_sort is set: rays of one origin neighbourhood (the tile) and one octant walk the BVH alike, which cuts
         // the trips a wave makes through the traversal loop by ~20 % (C2: SIMD efficiency of node steps 0.35 -> 0.44).
         // Ray and path state go through LDS so that the queue is written in slot order, coalesced, whatever the ranking.
-        __shared__ u32 s_cnt[129];
         __shared__ float s_stage[14][SEG];
-        u32 ls;
-        if (a.ray_sort) {
-            const u32 key = (nd.x < 0.0f ? 1u : 0u) | (nd.y < 0.0f ? 2u : 0u) | (nd.z < 0.0f ? 4u : 0u);
-            ls = block_rank_keyed(cont, key, s_cnt, total);
-        } else ls = block_rank(cont, s_wave, total);
+        const u32 ls = rank_sorted();
         const bool rad_zero = __syncthreads_or(cont && (as_u32(rad.x) | as_u32(rad.y) | as_u32(rad.z)) != 0u) == 0; // uniform
         if (threadIdx.x == 0) a.seg_count[inq ^ 1u][blockIdx.x] = total | (rad_zero ? SEG_RAD_ZERO : 0u);
         if (cont) {
@@ -593,7 +622,7 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         }
         return; // the fused pass has no gather queue
     }
-    u32 slot = blockIdx.x * SEG + block_rank(cont, s_wave, total);
+    u32 slot = blockIdx.x * SEG + rank_sorted(); // (sorted: the seven stores scatter inside the segment's 4 KB of each array)
     if (threadIdx.x == 0) a.seg_count[inq ^ 1u][blockIdx.x] = total;
     if (cont) {
         const RayQueue& q = a.q[inq ^ 1u];
