@@ -72,7 +72,7 @@ struct rt_ctx {
     bool stack_deep_ok = true; // RT_STACK_DEEP=0: deep trees always on the spilling stack (tuning aid)
     bool flat_enabled = true, flat_waves8 = true; u32 flat_instances = 0, flat_tris = 0, flat_first1 = 0;
     // inlined instance of the two-level walk (SceneView::inl_inst); RT_INLINE=0 switches it off (tuning aid)
-    int sort_box = 1; float flat_box[RT_FLAT_MAX_INSTANCES][6] = {}; u32 flat_big = 0; // RT_SORT_BOX
+    float sort_chord_pct = 0.5f; /* RT_SORT_CHORD */ int sort_box = 1; float flat_box[RT_FLAT_MAX_INSTANCES][6] = {}; u32 flat_big = 0; // RT_SORT_BOX
     bool inline_enabled = true; int inl_inst = -1; u32 inl_count = 0; const TriRec* inl_tris = nullptr; u32 inl_copy_bytes = 0; float inl_w2o[12] = {};
     PackedNode* d_flat_nodes = nullptr; FlatTri* d_flat_tris = nullptr; /* inside the d_flat_nodes allocation */ u32* d_flat_perm = nullptr;
     TreeInfo flat_info = {}; float flat_w2o[RT_FLAT_MAX_INSTANCES][12] = {}; double flat_build_ms = 0;
@@ -257,6 +257,17 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.xcd_bands = c->xcd_bands ? 1u : 0u;
     a.sort_box_on = (c->sort_box && c->flat_instances == 2u) ? 1u : 0u;
     memcpy(a.sort_box, c->flat_box[c->flat_big], sizeof a.sort_box);
+    a.sort_chord = 0.0f;
+    if (c->sort_box && c->sort_chord_pct > 0.0f && c->flat_instances == 0u && c->n_instances > 0u) {
+        // two levels: the box of the top level (the instances but the inlined one); a ray with a long way through it meets many instances
+        float diag = 0.0f;
+        for (int k = 0; k < 3; k++) {
+            const float h = 1.0f / c->tlas_info.inv_h[k];
+            a.sort_box[k] = c->tlas_info.ctr[k] - h; a.sort_box[3 + k] = c->tlas_info.ctr[k] + h; diag += 4.0f * h * h;
+        }
+        a.sort_chord = 0.01f * c->sort_chord_pct * sqrtf(diag);
+        a.sort_box_on = 2u;
+    }
     // rows 0..16 of the per-lane LDS stack of the 6-wave kernels, or rows 0..32 of the 5-wave "deep" kernels (rt_kernels.hip)
     a.stack_in_lds = !c->stack_lds_ok ? 0u : c->tlas_depth + c->max_blas_depth + 2 <= 16 ? 1u : (c->stack_deep_ok && c->tlas_depth + c->max_blas_depth + 2 <= 32) ? 2u : 0u;
     a.task_counter = c->d_task_counter; a.persistent_slots = c->persistent_slots;
@@ -587,6 +598,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
     if (const char* v = getenv("RT_XCD_BANDS")) c->xcd_bands = atoi(v);
     if (const char* v = getenv("RT_SORT_BOX")) c->sort_box = atoi(v);
+    if (const char* v = getenv("RT_SORT_CHORD")) c->sort_chord_pct = (float) atof(v);
     if (const char* v = getenv("RT_INLINE")) c->inline_enabled = atoi(v) != 0;
     if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
     if (const char* v = getenv("RT_STACK_LDS")) c->stack_lds_ok = atoi(v) != 0;

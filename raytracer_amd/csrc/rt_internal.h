@@ -147,7 +147,7 @@ struct PassArgs {
     u32 stack_in_lds;            // the trees are shallow enough for the LDS rows of the traversal stack alone (LaneStack<false>)
     u32 flat_waves8;             // one-instance flat tree shallow enough for 20 LDS rows: traversal kernels at 8 waves per SIMD
     u32 wave_major;              // queued traverse launches: task -> (segment, wave) mapping, see k_traverse (RT_WAVE_MAJOR)
-    float sort_box[6]; u32 sort_box_on; // k_shade: rays crossing this world box are queued behind the others (RT_SORT_BOX)
+    float sort_box[6]; float sort_chord; u32 sort_box_on; // k_shade rank_sorted: 1 = rays crossing this world box (the big mesh of a two-instance scene) are queued apart, 2 = by the length of their way through it (the top level's box); RT_SORT_BOX=0: neither
     u32 xcd_bands;               // traverse launches: the workgroups of one XCD take neighbouring tiles / segments, see k_traverse (RT_XCD_BANDS)
     u32 ray_sort;                // fused camera pass: survivors of a bounce are grouped by direction octant inside their segment (RT_RAY_SORT)
     SlotState st[2];             // fused camera pass: path state by queue slot

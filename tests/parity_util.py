@@ -1,5 +1,6 @@
 """Helpers shared by the GPU parity tests: run one scene description on the HIP product and on the CPU oracle and
 compare hit records (bit-exact ids, exact t/u/v), RNG streams, accumulators and render targets."""
+import os
 import numpy as np
 
 from raytracer_amd import _abi
@@ -32,6 +33,9 @@ def compare_images(gpu_acc, cpu_acc, rel=1e-4, rmse=1e-3):
     g, c = np.nan_to_num(gpu_acc.astype(np.float64)), np.nan_to_num(cpu_acc.astype(np.float64))
     err = np.abs(g - c)
     tol = rel * np.maximum(np.abs(c), 1e-6)
+    if os.environ.get("RT_PARITY_REPORT"):  # margin report: worst relative error of every comparison, one per line
+        with open(os.environ["RT_PARITY_REPORT"], "a") as f:
+            f.write("%s max_rel %.3e\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?"), float((err / np.maximum(np.abs(c), 1e-6)).max())))
     assert (err <= tol).all(), "accumulator max rel err %g at %s" % (float((err / np.maximum(np.abs(c), 1e-6)).max()),
                                                                      np.argwhere(err > tol)[0])
     assert float(np.sqrt(np.mean((g - c) ** 2))) < rmse
