@@ -6,7 +6,7 @@ import os
 from . import _abi
 from ._abi import *  # noqa: F401,F403  (re-export constants and struct types)
 
-_LIB_PATH = os.path.join(_abi.PKG_DIR, "librt_mi355x.so")
+_LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(_abi.PKG_DIR, "librt_mi355x.so")  # RT_LIB_PATH: another build of the same library (A/B of compile-time variants)
 _lib = _abi.load_library(_LIB_PATH)
 _lib.rt_last_error.restype = C.c_char_p
 _lib.rt_abi_version.restype = C.c_int

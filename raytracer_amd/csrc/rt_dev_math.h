@@ -152,6 +152,8 @@ struct RayPrep {
     float sx, sy, sz;  // d[kz + 1] / d[kz], d[kz + 2] / d[kz], 1 / d[kz]
 };
 
+// SHARED_DIVISOR: see below; for callers that prepare the rays of a whole wave together (the flat walk)
+template <bool SHARED_DIVISOR = false>
 RT_DEV RayPrep prepare_ray(f3 o, f3 d) {
     RayPrep r;
     const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
@@ -164,6 +166,30 @@ RT_DEV RayPrep prepare_ray(f3 o, f3 d) {
     r.o = mk3(z_over ? o.x : (y_over_x ? o.z : o.y), z_over ? o.y : (y_over_x ? o.x : o.z), z_over ? o.z : (y_over_x ? o.y : o.x));
     r.kz = kz;
     r.flip = dz < 0.0f ? 0x80000000u : 0u;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_SHARED_DIV)
+    // The three quotients share their divisor.  The compiler's IEEE division is v_div_scale (both operands), v_rcp, two
+    // Newton steps on the reciprocal, the quotient with two residual corrections, v_div_fmas, v_div_fixup: 11 instructions,
+    // of which the scaling and the fix-up do nothing unless an operand, the reciprocal or the quotient comes near the ends
+    // of the exponent range.  With all three operands in [2^-60, 2^60] (|d1|, |d2| <= |dz| by the choice of kz) they are
+    // idle, and the same sequence, operation for operation, needs the reciprocal's part once: 17 instructions for the three
+    // quotients instead of 33, the same bits.  A wave with any lane outside the range (a zero component, say) divides as before.
+    // Same-box A/B (profiles/r02_ab_shared_divisor.txt): C2 +1.0 %, C3 +0.45 %; at the instance entries of the two-level walk,
+    // where a few lanes of a wave prepare at a time, the vote costs more than the divisions saved (C5 -0.3 %): not used there.
+    const float small = fminf(fabsf(d1), fabsf(d2));
+    if (SHARED_DIVISOR && __all(fabsf(dz) <= 0x1p60f && small >= 0x1p-60f)) {
+        float rc = __builtin_amdgcn_rcpf(dz);
+        rc = __builtin_fmaf(__builtin_fmaf(-dz, rc, 1.0f), rc, rc);
+        float q = d1 * rc;
+        q = __builtin_fmaf(__builtin_fmaf(-dz, q, d1), rc, q);
+        r.sx = __builtin_fmaf(__builtin_fmaf(-dz, q, d1), rc, q);
+        q = d2 * rc;
+        q = __builtin_fmaf(__builtin_fmaf(-dz, q, d2), rc, q);
+        r.sy = __builtin_fmaf(__builtin_fmaf(-dz, q, d2), rc, q);
+        q = __builtin_fmaf(__builtin_fmaf(-dz, rc, 1.0f), rc, rc);
+        r.sz = __builtin_fmaf(__builtin_fmaf(-dz, q, 1.0f), rc, q);
+        return r;
+    }
+#endif
     r.sx = d1 / dz;
     r.sy = d2 / dz;
     r.sz = 1.0f / dz;

@@ -391,7 +391,7 @@ RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, 
         if (K > 1 && !__any(enters[i])) continue; // wave-uniform
         // the matrices are kernel arguments (scalar loads); CAMERA_ORIGIN: o is the camera's for every lane and the host has transformed it
         const f3 oo = CAMERA_ORIGIN ? mk3(sc.flat_cam_o[i][0], sc.flat_cam_o[i][1], sc.flat_cam_o[i][2]) : xform_point43(sc.flat_w2o[i], o);
-        rp = prepare_ray(oo, xform_dir43(sc.flat_w2o[i], d));
+        rp = prepare_ray<true>(oo, xform_dir43(sc.flat_w2o[i], d));
 #if defined(__HIP_DEVICE_COMPILE__)
         // computed here, once per ray: left alone the compiler keeps d[kz] instead of 1 / d[kz] and divides again at every leaf
         asm volatile("" : "+v"(rp.sx), "+v"(rp.sy), "+v"(rp.sz));
