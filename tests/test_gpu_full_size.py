@@ -116,6 +116,37 @@ def test_frames_in_flight_do_not_change_the_image(monkeypatch):
     assert len(results[("2", 3)][3]) > 0 and len(results[("2", 4)][3]) > 0
 
 
+def test_scheduling_switches_do_not_change_the_image(monkeypatch):
+    """Where a ray sits in its queue, which XCD traces its tile, whether the floor is inlined or the tree flat: none of it may
+    change a bit of the image.  Production path (no hit tap, frames in flight), five frames each: the bunny on its floor
+    and Cornell + translucent bunny (two-instance flat scenes: RT_SORT_BOX's crossing key, fused and unfused shade), the
+    instance field (two levels: chord classes, inlined floor) -- every switch off, one at a time, against all defaults."""
+    from raytracer_amd import api, distributed
+    cases = [scenes.bunny(960, 540, spp=2, bounces=3), scenes.cornell_bunny(480, 270, spp=2, bounces=3),
+             scenes.bunny_field(640, 360, spp=1, bounces=3, grid=24, count=500)]
+    switches = [None, "RT_SORT_BOX", "RT_RAY_SORT", "RT_XCD_BANDS", "RT_INLINE", "RT_FLAT", "RT_WAVE_MAJOR"]
+    images = {}
+    for sw in switches:
+        if sw: monkeypatch.setenv(sw, "0")
+        for k, scene in enumerate(cases):
+            rt = api.Raytracer(0)
+            try:
+                scene.setup(rt)
+                for f in range(5):
+                    distributed.render_frame(rt, scene.globals, f, 41)
+                images[(sw, k)] = (rt.read_accumulator(), rt.read_render_target())
+            finally:
+                rt.close()
+        if sw: monkeypatch.delenv(sw)
+    for k in range(len(cases)):
+        ref = images[(None, k)]
+        assert ref[0].any()
+        for sw in switches[1:]:
+            got = images[(sw, k)]
+            assert np.array_equal(ref[0].view(np.uint32), got[0].view(np.uint32)), (sw, k)
+            assert np.array_equal(ref[1], got[1]), (sw, k)
+
+
 def test_top_level_rebuilds_between_pipelined_frames(monkeypatch):
     """The reference rebuilds the top level every frame (raytracing.cpp:652-676).  A rebuild, like every entry point other
     than a dispatch, first drains both lanes of the frame pipeline: frames rendered with a moving instance, with and
