@@ -278,6 +278,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     for (int k = 0; k < 3; k++) a.camera_origin[k] = c->g.camera_to_world[12 + k] / c->g.camera_to_world[15];
     a.fudge = (c->flags & RT_FLAG_ENABLE_SSS) ? c->g.translucent_bssrdf_fudge : 0.0f;
     a.width = c->width; a.height = c->height;
+    a.inv_size[0] = 1.0f / (float) c->width; a.inv_size[1] = 1.0f / (float) c->height;
     a.tile_rank = c->tile_rank; a.tile_world = c->tile_world;
     a.tiles_x = (c->width + 31) / 32; a.tiles_y = (c->height + 31) / 32;
     u32 n_tiles = a.tiles_x * a.tiles_y;

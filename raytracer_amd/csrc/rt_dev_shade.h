@@ -126,15 +126,17 @@ RT_DEV void shade_ray(const ShadeScene& sc, const RtGlobals& g, float fudge, f3 
 // camera ray for pixel (px, py), raytracing.hlsl:141-149; draws two random11 (x first, Q6)
 // `camera_origin` = camera_to_world[3].xyz / camera_to_world[3].w: the same for every pixel, so the host divides
 // (IEEE division, same quotient) instead of every lane
-RT_DEV void camera_ray(const RtGlobals& g, const float* camera_origin, u32 px, u32 py, u32 width, u32 height, u32& rng, f3& origin, f3& direction) {
+// `inv_size` = { 1 / width, 1 / height } as the host's IEEE quotients: x / width is then x * inv + one residual correction
+// (quotient_by_reciprocal, rt_dev_math.h), the correctly rounded quotient in 3 instructions instead of 11
+RT_DEV void camera_ray(const RtGlobals& g, const float* camera_origin, const float* inv_size, u32 px, u32 py, u32 width, u32 height, u32& rng, f3& origin, f3& direction) {
     const float* m = g.camera_to_world;
     origin = mk3(camera_origin[0], camera_origin[1], camera_origin[2]);
     float dx = (float) px + 0.5f, dy = (float) py + 0.5f;
     float jx = random11(rng);
     float jy = random11(rng);
     dx = dx + 0.5f * jx; dy = dy + 0.5f * jy;
-    dx = 2.0f * dx / (float) width - 1.0f;
-    dy = 2.0f * dy / (float) height - 1.0f;
+    dx = quotient_by_reciprocal(2.0f * dx, (float) width, inv_size[0]) - 1.0f;
+    dy = quotient_by_reciprocal(2.0f * dy, (float) height, inv_size[1]) - 1.0f;
     dx = dx * g.camera_aspect;
     dy = dy * -1.0f;
     float dz = -g.camera_focal_length;

@@ -164,7 +164,7 @@ RT_DEV bool thread_pixel(const PassArgs& a, u32 t, u32& px, u32& py) {
 // and a 3x3 transform), which is cheaper than a 28-byte round trip through the ray queue.
 RT_DEV void primary_ray(const PassArgs& a, u32 px, u32 py, u32 pixel, u32 sample_index, u32& rng, f3& o, f3& d) {
     rng = sample_index == 0 ? hash_u3(px, py, a.g.frame_rng * (u32) (a.g.accumulator_count != 0)) : a.ps.rng[pixel];
-    camera_ray(a.g, a.camera_origin, px, py, a.width, a.height, rng, o, d);
+    camera_ray(a.g, a.camera_origin, a.inv_size, px, py, a.width, a.height, rng, o, d);
 }
 
 // the tail of camera_rgen (raytracing.hlsl:153-161): `tot` = sum of the dispatch's samples of one pixel
