@@ -73,6 +73,7 @@ struct rt_ctx {
     bool flat_enabled = true, flat_waves8 = true; u32 flat_instances = 0, flat_tris = 0, flat_first1 = 0;
     // inlined instance of the two-level walk (SceneView::inl_inst); RT_INLINE=0 switches it off (tuning aid)
     float sort_chord_pct = 0.5f; /* RT_SORT_CHORD */ int sort_box = 1; float flat_box[RT_FLAT_MAX_INSTANCES][6] = {}; u32 flat_big = 0; // RT_SORT_BOX
+    int flat_inl_inst = -1; u32 flat_inst0 = 0; bool flat_inline_enabled = true; /* RT_FLAT_INLINE */
     bool inline_enabled = true; int inl_inst = -1; u32 inl_count = 0; const TriRec* inl_tris = nullptr; u32 inl_copy_bytes = 0; float inl_w2o[12] = {};
     PackedNode* d_flat_nodes = nullptr; FlatTri* d_flat_tris = nullptr; /* inside the d_flat_nodes allocation */ u32* d_flat_perm = nullptr;
     TreeInfo flat_info = {}; float flat_w2o[RT_FLAT_MAX_INSTANCES][12] = {}; double flat_build_ms = 0;
@@ -255,7 +256,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.ray_sort = c->ray_sort ? 1u : 0u;
     a.wave_major = c->wave_major ? 1u : 0u;
     a.xcd_bands = c->xcd_bands ? 1u : 0u;
-    a.sort_box_on = (c->sort_box && c->flat_instances == 2u) ? 1u : 0u;
+    a.sort_box_on = (c->sort_box && (c->flat_instances == 2u || (c->flat_instances == 1u && c->flat_inl_inst >= 0))) ? 1u : 0u;
     memcpy(a.sort_box, c->flat_box[c->flat_big], sizeof a.sort_box);
     a.sort_chord = 0.0f;
     if (c->sort_box && c->sort_chord_pct > 0.0f && c->flat_instances == 0u && c->n_instances > 0u) {
@@ -291,6 +292,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.scene.tlas_nodes = c->d_tlas_nodes; a.scene.insts = c->d_inst_rec;
     for (int k = 0; k < 3; k++) { a.scene.tlas_ctr[k] = c->tlas_info.ctr[k]; a.scene.tlas_inv_h[k] = c->tlas_info.inv_h[k]; }
     a.scene.tlas_bound = c->tlas_info.bound;
+    a.scene.flat_inl_inst = c->flat_instances ? c->flat_inl_inst : -1; a.scene.flat_inst0 = c->flat_inst0;
     a.scene.inl_inst = c->inl_inst; a.scene.inl_count = c->inl_count; a.scene.n_insts = c->n_instances; a.scene.inl_tris = c->inl_tris; a.scene.inl_copy_bytes = c->inl_copy_bytes;
     memcpy(a.scene.inl_w2o, c->inl_w2o, sizeof c->inl_w2o);
     a.scene.flat_instances = c->flat_instances;
@@ -471,6 +473,7 @@ void free_blas(Blas& b) {
 }
 
 void free_flat_tree(rt_ctx* c) {
+    c->flat_inl_inst = -1; c->flat_inst0 = 0;
     dev_free(c->d_flat_nodes); c->d_flat_tris = nullptr; dev_free(c->d_flat_perm);
     c->flat_instances = 0; c->flat_tris = 0; c->flat_build_ms = 0;
 }
@@ -483,6 +486,15 @@ int build_flat_tree(rt_ctx* c, const RtInstance* instances, int n, const std::ve
     if (!c->flat_enabled || n > RT_FLAT_MAX_INSTANCES) return RT_OK;
     FlatSources src; memset(&src, 0, sizeof src);
     uint64_t total = 0;
+    // two instances of which one has at most RT_INLINE_MAX_TRIS triangles (a mesh on a floor): the tree holds the other one
+    // alone and every ray tests the small one's triangles first (SceneView::flat_inl_inst)
+    int small = -1;
+    if (n == 2 && c->flat_inline_enabled) {
+        const u32 t0 = c->blas[instances[0].blas].n_tris, t1 = c->blas[instances[1].blas].n_tris;
+        if (t1 <= RT_INLINE_MAX_TRIS && t0 > t1) small = 1; else if (t0 <= RT_INLINE_MAX_TRIS && t1 > t0) small = 0;
+    }
+    const int first_inst = small == 0 ? 1 : 0, n_all = n;
+    if (small >= 0) { instances += first_inst; n = 1; } // (rec[] keeps the caller's numbering: rec[first_inst] below)
     for (int i = 0; i < n; i++) {
         const Blas& b = c->blas[instances[i].blas];
         FlatSource& fs = src.s[i];
@@ -509,7 +521,7 @@ int build_flat_tree(rt_ctx* c, const RtInstance* instances, int n, const std::ve
         if (brc) return brc;
         RT_HIP(hipEventRecord(c->build_ev[1], c->stream));
         RT_HIP(hipMemcpyAsync(&c->flat_info, c->lbvh.tree_info, sizeof c->flat_info, hipMemcpyDeviceToHost, c->stream));
-        if (n > 1) RT_HIP(hipMemcpyAsync(c->flat_box, d_sub, sizeof c->flat_box, hipMemcpyDeviceToHost, c->stream));
+        RT_HIP(hipMemcpyAsync(c->flat_box, d_sub, (n > 1 ? 2 : 1) * sizeof c->flat_box[0], hipMemcpyDeviceToHost, c->stream)); // world boxes of the instances in the tree
         c->flat_big = (n > 1 && src.s[1].n_tris > src.s[0].n_tris) ? 1u : 0u;
         return RT_OK;
     };
@@ -518,7 +530,14 @@ int build_flat_tree(rt_ctx* c, const RtInstance* instances, int n, const std::ve
     float ms = 0; RT_HIP(hipEventElapsedTime(&ms, c->build_ev[0], c->build_ev[1]));
     // k_traverse<.., FLAT> keeps the whole stack in its 26 LDS rows: sentinel + one entry per level + the row above the top
     if (c->flat_info.depth + 2 > 26) { free_flat_tree(c); return RT_OK; }
-    for (int i = 0; i < n; i++) memcpy(c->flat_w2o[i], rec[i].world_to_object, 48);
+    for (int i = 0; i < n; i++) memcpy(c->flat_w2o[i], rec[first_inst + i].world_to_object, 48);
+    c->flat_inl_inst = small; c->flat_inst0 = (u32) first_inst;
+    if (small >= 0) {
+        const Blas& b = c->blas[(instances - first_inst)[small].blas];
+        c->inl_count = b.n_tris; c->inl_tris = b.d_tris; c->inl_copy_bytes = (u32) (b.n_tris * sizeof(TriRec));
+        memcpy(c->inl_w2o, rec[small].world_to_object, 48);
+    }
+    (void) n_all;
     c->flat_instances = (u32) n; c->flat_tris = nt; c->flat_build_ms = ms; c->flat_first1 = n > 1 ? src.s[1].first : nt;
     return RT_OK;
 }
@@ -601,6 +620,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_SORT_BOX")) c->sort_box = atoi(v);
     if (const char* v = getenv("RT_SORT_CHORD")) c->sort_chord_pct = (float) atof(v);
     if (const char* v = getenv("RT_INLINE")) c->inline_enabled = atoi(v) != 0;
+    if (const char* v = getenv("RT_FLAT_INLINE")) c->flat_inline_enabled = atoi(v) != 0;
     if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
     if (const char* v = getenv("RT_STACK_LDS")) c->stack_lds_ok = atoi(v) != 0;
     if (const char* v = getenv("RT_FLAT")) c->flat_enabled = atoi(v) != 0;

@@ -91,6 +91,10 @@ struct SceneView {
     // other n_insts - 1 instances: its primitive p is instance p, except p == inl_inst, which is the last instance
     // (rt_build_tlas moves the last box into the free slot).
     int inl_inst;
+    // the same for a flat scene of two instances of which one is that small (a mesh on a floor): the flat tree then holds the
+    // other one alone (instance flat_inst0) and walks like a one-instance scene, 8 waves per SIMD (trace_flat<1, .., INL>)
+    int flat_inl_inst;
+    u32 flat_inst0;
     u32 inl_count;           // triangles of the inlined instance
     u32 n_insts;
     const TriRec* inl_tris;  // its TriRec array (three copies of inl_copy_bytes)
@@ -365,7 +369,7 @@ RT_DEV RayPrep flat_pick(const FlatPreps<K>& p, u32 inst) {
     r.sx = one ? b.sx : a.sx; r.sy = one ? b.sy : a.sy; r.sz = one ? b.sz : a.sz;
     return r;
 }
-template <int K, class Stack, bool COUNT, bool SPECULATE, bool CAMERA_ORIGIN = false>
+template <int K, class Stack, bool COUNT, bool SPECULATE, bool CAMERA_ORIGIN = false, bool INL = false>
 RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, Stack& st, HitOut& out, TraverseCounters& cnt) {
     static_assert(K >= 1 && K <= RT_FLAT_MAX_INSTANCES && RT_FLAT_MAX_INSTANCES == 2, "flat_pick selects between two preparations");
     ClosestHit best; best.t = tmax; best.u_num = 0.0f; best.v_num = 0.0f; best.det = 1.0f; best.inst = -1; best.tri = -1; best.prim_global = 0;
@@ -379,16 +383,30 @@ RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, 
     // here, says which instances a ray can reach at all, and the wave prepares the ray (transform, shear with three divisions:
     // ~95 vector instructions each) only for the instances that one of its rays enters -- a wave of sky or floor pixels skips
     // one or both.  The step is the one the loop would have taken first: same stack, same order, same counters.
+    static_assert(!INL || K == 1, "the inlined instance goes with a tree of one instance");
+    if (INL && cur != RT_TRAVERSAL_DONE) { // the small instance's triangles first, all lanes together (SceneView::flat_inl_inst)
+        const RayPrep irp = prepare_ray<true>(xform_point43(sc.inl_w2o, o), xform_dir43(sc.inl_w2o, d));
+        const RT_GLOBAL TriRec* tr = (const RT_GLOBAL TriRec*) ((const RT_GLOBAL char*) sc.inl_tris + (size_t) ((u32) irp.kz * sc.inl_copy_bytes));
+        for (u32 j = 0; j < sc.inl_count; j++) {
+            const Quad a = ldq(tr + j, 0), b = ldq(tr + j, 1), c = ldq(tr + j, 2);
+            if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
+            triangle_candidate(irp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), tmin, sc.flat_inl_inst, (int) j, as_u32(c.y), best);
+        }
+    }
     bool enters[2] = { true, true };
     if (K > 1) {
         enters[0] = false; enters[1] = false;
         if (cur >= 0) cur = node_step<Stack, COUNT, true>(nodes, br, cur, tmin, best.t, st, cnt, &enters[0], &enters[1]);
+    } else if (INL) { // the root's step first here too: a wave none of whose rays reaches the mesh's box (or gets past the hit above) prepares nothing
+        bool e0 = false, e1 = false;
+        if (cur >= 0) cur = node_step<Stack, COUNT, true>(nodes, br, cur, tmin, best.t, st, cnt, &e0, &e1);
+        enters[0] = e0 || e1;
     }
     FlatPreps<K> preps;
     for (int i = 0; i < K; i++) {
         RayPrep& rp = preps.rp[i];
         rp.o = mk3(0.0f, 0.0f, 0.0f); rp.kz = 0; rp.flip = 0u; rp.sx = 0.0f; rp.sy = 0.0f; rp.sz = 0.0f;
-        if (K > 1 && !__any(enters[i])) continue; // wave-uniform
+        if ((K > 1 || INL) && !__any(enters[i])) continue; // wave-uniform
         // the matrices are kernel arguments (scalar loads); CAMERA_ORIGIN: o is the camera's for every lane and the host has transformed it
         const f3 oo = CAMERA_ORIGIN ? mk3(sc.flat_cam_o[i][0], sc.flat_cam_o[i][1], sc.flat_cam_o[i][2]) : xform_point43(sc.flat_w2o[i], o);
         rp = prepare_ray<true>(oo, xform_dir43(sc.flat_w2o[i], d));
@@ -422,8 +440,8 @@ RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, 
         // ---- leaf: up to 8 triangles of one instance ---------------------------------------------------------------
         const u32 v = (u32) ~leaf;
         const u32 first = v >> 3, count = (v & 7u) + 1u;
-        const u32 inst = K > 1 && first >= sc.flat_first1 ? 1u : 0u;
-        const RayPrep rp = flat_pick<K>(preps, inst);
+        const u32 inst = K > 1 ? (first >= sc.flat_first1 ? 1u : 0u) : (INL ? sc.flat_inst0 : 0u);
+        const RayPrep rp = flat_pick<K>(preps, K > 1 ? inst : 0u);
         const RT_GLOBAL char* tris0 = (const RT_GLOBAL char*) sc.flat_tris + ((size_t) first * sizeof(FlatTri) + (size_t) ((u32) rp.kz * sc.flat_copy_bytes));
         for (u32 k = 0; k < count; k++) {
             const RT_GLOBAL FlatTri* tr = (const RT_GLOBAL FlatTri*) (tris0 + k * sizeof(FlatTri));

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
             st.spill_stride = a.n_paths; st.sp = 0;
             HitOut best;
             if (FLAT > 0) {
-                trace_flat<(FLAT > 0 ? FLAT : 1), Stack, COUNT, !PRIMARY, PRIMARY>(a.scene, o, d, a.tmin, a.tmax, st, best, cnt);
+                trace_flat<(FLAT == 2 ? 2 : 1), Stack, COUNT, !PRIMARY, PRIMARY, FLAT == 3>(a.scene, o, d, a.tmin, a.tmax, st, best, cnt); // FLAT = 3: one instance in the tree, a small one tested first (SceneView::flat_inl_inst)
             } else {
                 TraceState S;
                 trace_begin(a.scene, o, d, a.tmax, S);
@@ -1021,6 +1021,17 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
         dim3 pgrid(a.persistent_slots);
         if (primary) hipLaunchKernelGGL((k_traverse<false, 5, true, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
         else hipLaunchKernelGGL((k_traverse<false, 5, false, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
+    } else if (a.scene.flat_instances == 1u && a.scene.flat_inl_inst >= 0) {
+        // one tree over the big instance of two, the small one tested first
+        if (primary) {
+            if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+            else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, true, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+            else hipLaunchKernelGGL((k_traverse<false, 6, true, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        } else {
+            if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+            else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, false, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+            else hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        }
     } else if (a.scene.flat_instances == 1u || a.scene.flat_instances == 2u) {
         // one tree over the triangles of all (one or two) instances; count_traversal: the same walk with the counters on
         const bool two = a.scene.flat_instances == 2u;

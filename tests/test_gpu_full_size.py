@@ -124,7 +124,7 @@ def test_scheduling_switches_do_not_change_the_image(monkeypatch):
     from raytracer_amd import api, distributed
     cases = [scenes.bunny(960, 540, spp=2, bounces=3), scenes.cornell_bunny(480, 270, spp=2, bounces=3),
              scenes.bunny_field(640, 360, spp=1, bounces=3, grid=24, count=500)]
-    switches = [None, "RT_SORT_BOX", "RT_RAY_SORT", "RT_XCD_BANDS", "RT_INLINE", "RT_FLAT", "RT_WAVE_MAJOR"]
+    switches = [None, "RT_SORT_BOX", "RT_RAY_SORT", "RT_XCD_BANDS", "RT_INLINE", "RT_FLAT_INLINE", "RT_FLAT", "RT_WAVE_MAJOR"]
     images = {}
     for sw in switches:
         if sw: monkeypatch.setenv(sw, "0")

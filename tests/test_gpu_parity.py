@@ -199,3 +199,21 @@ def test_inlined_instance_and_plain_two_levels_agree_with_the_oracle(oracle_mod,
     s.instances = [s.instances[1], s.instances[0], s.instances[2],
                    (host.affine_transform(0.05, 0.3, (-0.6, 0.4, 0.4)), 1)]                              # floor in the middle + a small copy of it
     _check_scene(s, oracle_mod)
+
+
+@pytest.mark.parametrize("flat_inline", ["0", "1"])
+def test_small_instance_of_a_flat_pair_tested_first(oracle_mod, monkeypatch, flat_inline):
+    """two instances of which one has at most 8 triangles (the bunny on its floor, the cube under its light): the flat tree holds
+    the big one alone and every ray tests the small one's triangles before the walk (RT_FLAT_INLINE=1, the default:
+    rt_dev_scene.h SceneView::flat_inl_inst) -- same hits as with both in the tree (RT_FLAT_INLINE=0).  Both orders of the
+    pair, so that the tree's instance is index 0 and index 1; a pair of two small instances keeps both in the tree."""
+    from raytracer_amd import host
+    monkeypatch.setenv("RT_FLAT_INLINE", flat_inline)      # read at rt_create
+    s = scenes.bunny(128, 72, spp=1, bounces=3)
+    _check_scene(s, oracle_mod, frames=2)
+    s.instances = [s.instances[1], s.instances[0]]
+    _check_scene(s, oracle_mod)
+    _check_scene(scenes.debug_cube(96, 96, spp=2, bounces=2), oracle_mod)
+    q = scenes.debug_cube(64, 64, spp=1, bounces=2)
+    q.instances = [q.instances[1], (host.affine_transform(0.5, 0.4, (0.1, 0.0, -0.3)), q.instances[1][1])]   # two quads
+    _check_scene(q, oracle_mod)
