@@ -600,7 +600,7 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         // first: +1.2 %); the unfused pass, whose seven stores per ray scatter with the key, does best with this one bit alone,
         // crossing rays first (C4 +8.7 %; last: +5.5 %; with the octants: +3.6 %)
         if (!FUSED) return block_rank_keyed<3>(cont, cross ^ 1u, s_cnt, total);
-        return block_rank_keyed<4>(cont, key | (cross << 3), s_cnt, total);
+        return block_rank_keyed<4>(cont, key | ((a.sort_box_on == 3u ? cross ^ 1u : cross) << 3), s_cnt, total);
     };
     if (FUSED) {
         // Survivors are compacted to the front of the segment, grouped by the octant of their new direction when
