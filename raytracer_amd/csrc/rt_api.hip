@@ -74,6 +74,7 @@ struct rt_ctx {
     // inlined instance of the two-level walk (SceneView::inl_inst); RT_INLINE=0 switches it off (tuning aid)
     float sort_chord_pct = 0.5f; /* RT_SORT_CHORD */ int sort_box = 1; float flat_box[RT_FLAT_MAX_INSTANCES][6] = {}; u32 flat_big = 0; // RT_SORT_BOX
     int flat_inl_inst = -1; u32 flat_inst0 = 0; bool flat_inline_enabled = true; /* RT_FLAT_INLINE */
+    float inl_box[RT_INLINE_MAX_TRIS][6] = {}; u32 inl_box_same = 0;
     bool inline_enabled = true; int inl_inst = -1; u32 inl_count = 0; const TriRec* inl_tris = nullptr; u32 inl_copy_bytes = 0; float inl_w2o[12] = {};
     PackedNode* d_flat_nodes = nullptr; FlatTri* d_flat_tris = nullptr; /* inside the d_flat_nodes allocation */ u32* d_flat_perm = nullptr;
     TreeInfo flat_info = {}; float flat_w2o[RT_FLAT_MAX_INSTANCES][12] = {}; double flat_build_ms = 0;
@@ -295,6 +296,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.scene.flat_inl_inst = c->flat_instances ? c->flat_inl_inst : -1; a.scene.flat_inst0 = c->flat_inst0;
     a.scene.inl_inst = c->inl_inst; a.scene.inl_count = c->inl_count; a.scene.n_insts = c->n_instances; a.scene.inl_tris = c->inl_tris; a.scene.inl_copy_bytes = c->inl_copy_bytes;
     memcpy(a.scene.inl_w2o, c->inl_w2o, sizeof c->inl_w2o);
+    memcpy(a.scene.inl_box, c->inl_box, sizeof c->inl_box); a.scene.inl_box_same = c->inl_box_same;
     a.scene.flat_instances = c->flat_instances;
     a.flat_waves8 = (c->flat_waves8 && c->flat_instances == 1 && c->flat_info.depth + 2 <= 20) ? 1u : 0u;
     if (c->flat_instances) {
@@ -472,6 +474,35 @@ void free_blas(Blas& b) {
     dev_free(b.d_nodes); b.d_tris = nullptr; dev_free(b.d_perm); dev_free(b.d_inv_perm);
 }
 
+// world boxes of the (at most RT_INLINE_MAX_TRIS) triangles of an inlined instance, in TriRec order, for SceneView::inl_box:
+// grown by 1e-4 of the largest coordinate, far beyond the rounding of the slab test that uses them and of the
+// object-space triangle test behind it
+int set_inline_boxes(rt_ctx* c, const Blas& b, const float* o2w) {
+    TriRec t[RT_INLINE_MAX_TRIS];
+    const u32 k = b.n_tris;
+    if (k == 0 || k > RT_INLINE_MAX_TRIS) { set_error("set_inline_boxes: %u triangles", k); return RT_ERR_INVALID; }
+    RT_HIP(hipStreamSynchronize(c->stream));
+    RT_HIP(hipMemcpy(t, b.d_tris + 2 * (size_t) k, k * sizeof(TriRec), hipMemcpyDeviceToHost)); // copy 2: coordinates in their natural order
+    double amax = 0.0;
+    double lo[RT_INLINE_MAX_TRIS][3], hi[RT_INLINE_MAX_TRIS][3];
+    for (u32 j = 0; j < k; j++) {
+        const float* v[3] = { t[j].v0, t[j].v1, t[j].v2 };
+        for (int a = 0; a < 3; a++) { lo[j][a] = 1e300; hi[j][a] = -1e300; }
+        for (int q = 0; q < 3; q++)
+            for (int a = 0; a < 3; a++) {
+                const double w = (double) v[q][0] * o2w[a] + (double) v[q][1] * o2w[4 + a] + (double) v[q][2] * o2w[8 + a] + o2w[12 + a];
+                lo[j][a] = std::min(lo[j][a], w); hi[j][a] = std::max(hi[j][a], w); amax = std::max(amax, fabs(w));
+            }
+    }
+    const double pad = 1.0e-4 * amax + 1.0e-30;
+    c->inl_box_same = 0;
+    for (u32 j = 0; j < k; j++) {
+        for (int a = 0; a < 3; a++) { c->inl_box[j][a] = (float) (lo[j][a] - pad); c->inl_box[j][3 + a] = (float) (hi[j][a] + pad); }
+        if (j > 0 && memcmp(c->inl_box[j], c->inl_box[j - 1], sizeof c->inl_box[j]) == 0) c->inl_box_same |= 1u << j;
+    }
+    return RT_OK;
+}
+
 void free_flat_tree(rt_ctx* c) {
     c->flat_inl_inst = -1; c->flat_inst0 = 0;
     dev_free(c->d_flat_nodes); c->d_flat_tris = nullptr; dev_free(c->d_flat_perm);
@@ -536,6 +567,7 @@ int build_flat_tree(rt_ctx* c, const RtInstance* instances, int n, const std::ve
         const Blas& b = c->blas[(instances - first_inst)[small].blas];
         c->inl_count = b.n_tris; c->inl_tris = b.d_tris; c->inl_copy_bytes = (u32) (b.n_tris * sizeof(TriRec));
         memcpy(c->inl_w2o, rec[small].world_to_object, 48);
+        int brc = set_inline_boxes(c, b, (instances - first_inst)[small].transform); if (brc) { c->flat_inl_inst = -1; return brc; }
     }
     (void) n_all;
     c->flat_instances = (u32) n; c->flat_tris = nt; c->flat_build_ms = ms; c->flat_first1 = n > 1 ? src.s[1].first : nt;
@@ -877,6 +909,7 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
         if (c->inl_inst != n - 1) { rc = lbvh_move_box(c->stream, c->lbvh, (u32) c->inl_inst, (u32) n - 1u); if (rc) { c->inl_inst = -1; return rc; } }
         c->inl_count = inl_k; c->inl_tris = b.d_tris; c->inl_copy_bytes = (u32) (b.n_tris * sizeof(TriRec));
         memcpy(c->inl_w2o, rec[c->inl_inst].world_to_object, 48);
+        rc = set_inline_boxes(c, b, instances[c->inl_inst].transform); if (rc) { c->inl_inst = -1; return rc; }
     }
     rc = lbvh_build(c->stream, c->lbvh, &c->ploc, &c->sah, c->bvh_builder, c->sah_tri, n_prims, 1, true, c->d_tlas_nodes, c->d_tlas_perm); if (rc) { c->inl_inst = -1; return rc; }
     RT_HIP(hipEventRecord(c->build_ev[1], c->stream));

@@ -100,6 +100,10 @@ struct SceneView {
     const TriRec* inl_tris;  // its TriRec array (three copies of inl_copy_bytes)
     u32 inl_copy_bytes;
     float inl_w2o[12];
+    // world boxes of those triangles, grown by 1e-4 of the scene's reach (rt_api.hip set_inline_boxes): a triangle whose box
+    // no ray of the wave meets is not tested, and a wave that meets none of them does not prepare its rays for the instance
+    float inl_box[RT_INLINE_MAX_TRIS][6];
+    u32 inl_box_same;        // bit j: the box of triangle j is the box of triangle j - 1 (the two halves of a quad)
     // flat tree (flat_instances = 0: none, traverse the two levels)
     const PackedNode* flat_nodes;
     const FlatTri* flat_tris;
@@ -292,6 +296,40 @@ RT_DEV int node_step(const RT_GLOBAL PackedNode* nodes, const BoxRay& r, int cur
     return any ? next : top;
 }
 
+// The triangles of the inlined instance (SceneView::inl_inst / flat_inl_inst), before the walk, all lanes together.
+// The box test is a plain slab test in world space with the hardware reciprocal: the boxes are grown far beyond its
+// rounding (1e-4 of the scene's reach against ~1e-7 of the coordinates) and the comparison has a relative slack of 1e-5 on
+// top, so a ray that the triangle test would accept is never turned away; which triangles get tested changes no result.
+template <bool COUNT>
+RT_DEV void inlined_triangles_first(const SceneView& sc, f3 o, f3 d, float tmin, int inst, ClosestHit& best, TraverseCounters& cnt) {
+    u32 need = 0; // bit j: some ray of the wave meets the box of triangle j (wave-uniform)
+    {
+        const float ix = fast_rcp(d.x), iy = fast_rcp(d.y), iz = fast_rcp(d.z);
+        bool in_box = false;
+        for (u32 j = 0; j < sc.inl_count; j++) {
+            if (!((sc.inl_box_same >> j) & 1u)) {
+                const float* b = sc.inl_box[j];
+                const float x0 = (b[0] - o.x) * ix, x1 = (b[3] - o.x) * ix;
+                const float y0 = (b[1] - o.y) * iy, y1 = (b[4] - o.y) * iy;
+                const float z0 = (b[2] - o.z) * iz, z1 = (b[5] - o.z) * iz;
+                const float en = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+                const float ex = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), best.t));
+                in_box = en * 0.99999f <= ex * 1.00001f;
+            }
+            if (__any(in_box)) need |= 1u << j;
+        }
+    }
+    if (need == 0u) return;
+    const RayPrep irp = prepare_ray<true>(xform_point43(sc.inl_w2o, o), xform_dir43(sc.inl_w2o, d));
+    const RT_GLOBAL TriRec* tr = (const RT_GLOBAL TriRec*) ((const RT_GLOBAL char*) sc.inl_tris + (size_t) ((u32) irp.kz * sc.inl_copy_bytes));
+    for (u32 j = 0; j < sc.inl_count; j++) {
+        if (!((need >> j) & 1u)) continue;
+        const Quad a = ldq(tr + j, 0), b = ldq(tr + j, 1), c = ldq(tr + j, 2);
+        if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
+        triangle_candidate(irp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), tmin, inst, (int) j, as_u32(c.y), best);
+    }
+}
+
 // Runs the ray to the end; S.best is then final (t = +inf for a miss).
 // `Stack` provides reset() / top() / put(v, really) / push(v) / pop(), the stack pointer `sp` and a side store of nine
 // floats (save_side / load_side) for the top-level box-test constants; COUNT enables the
@@ -304,13 +342,7 @@ RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, S
     st.reset();
     { const BoxRay& b = S.br; const float v[9] = { b.idx, b.idy, b.idz, b.cnx, b.cny, b.cnz, b.cfx, b.cfy, b.cfz }; st.save_side(v); }
     if (sc.inl_inst >= 0 && S.cur != RT_TRAVERSAL_DONE) { // the triangles of the inlined instance first (SceneView::inl_inst); uniform but for NaN rays
-        const RayPrep irp = prepare_ray(xform_point43(sc.inl_w2o, o), xform_dir43(sc.inl_w2o, d));
-        const RT_GLOBAL TriRec* tr = (const RT_GLOBAL TriRec*) ((const RT_GLOBAL char*) sc.inl_tris + (size_t) ((u32) irp.kz * sc.inl_copy_bytes));
-        for (u32 j = 0; j < sc.inl_count; j++) {
-            Quad a = ldq(tr + j, 0), b = ldq(tr + j, 1), c = ldq(tr + j, 2);
-            if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
-            triangle_candidate(irp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), tmin, sc.inl_inst, (int) j, as_u32(c.y), S.ch);
-        }
+        inlined_triangles_first<COUNT>(sc, o, d, tmin, sc.inl_inst, S.ch, cnt);
         if (sc.n_insts < 2u) S.cur = RT_TRAVERSAL_DONE; // nothing else in the scene (cannot happen: such scenes get a flat tree)
     }
     for (;;) {
@@ -384,15 +416,7 @@ RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, 
     // ~95 vector instructions each) only for the instances that one of its rays enters -- a wave of sky or floor pixels skips
     // one or both.  The step is the one the loop would have taken first: same stack, same order, same counters.
     static_assert(!INL || K == 1, "the inlined instance goes with a tree of one instance");
-    if (INL && cur != RT_TRAVERSAL_DONE) { // the small instance's triangles first, all lanes together (SceneView::flat_inl_inst)
-        const RayPrep irp = prepare_ray<true>(xform_point43(sc.inl_w2o, o), xform_dir43(sc.inl_w2o, d));
-        const RT_GLOBAL TriRec* tr = (const RT_GLOBAL TriRec*) ((const RT_GLOBAL char*) sc.inl_tris + (size_t) ((u32) irp.kz * sc.inl_copy_bytes));
-        for (u32 j = 0; j < sc.inl_count; j++) {
-            const Quad a = ldq(tr + j, 0), b = ldq(tr + j, 1), c = ldq(tr + j, 2);
-            if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
-            triangle_candidate(irp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), tmin, sc.flat_inl_inst, (int) j, as_u32(c.y), best);
-        }
-    }
+    if (INL && cur != RT_TRAVERSAL_DONE) inlined_triangles_first<COUNT>(sc, o, d, tmin, sc.flat_inl_inst, best, cnt); // (SceneView::flat_inl_inst)
     bool enters[2] = { true, true };
     if (K > 1) {
         enters[0] = false; enters[1] = false;
