@@ -297,6 +297,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.scene.inl_inst = c->inl_inst; a.scene.inl_count = c->inl_count; a.scene.n_insts = c->n_instances; a.scene.inl_tris = c->inl_tris; a.scene.inl_copy_bytes = c->inl_copy_bytes;
     memcpy(a.scene.inl_w2o, c->inl_w2o, sizeof c->inl_w2o);
     memcpy(a.scene.inl_box, c->inl_box, sizeof c->inl_box); a.scene.inl_box_same = c->inl_box_same;
+    for (int k = 0; k < 3; k++) { const float* m = c->inl_w2o; const float* p = a.camera_origin; a.scene.inl_cam_o[k] = p[0] * m[k] + p[1] * m[3 + k] + p[2] * m[6 + k] + m[9 + k]; } // xform_point43, operation for operation
     a.scene.flat_instances = c->flat_instances;
     a.flat_waves8 = (c->flat_waves8 && c->flat_instances == 1 && c->flat_info.depth + 2 <= 20) ? 1u : 0u;
     if (c->flat_instances) {

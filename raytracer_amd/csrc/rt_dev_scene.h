@@ -100,6 +100,7 @@ struct SceneView {
     const TriRec* inl_tris;  // its TriRec array (three copies of inl_copy_bytes)
     u32 inl_copy_bytes;
     float inl_w2o[12];
+    float inl_cam_o[3];      // the camera origin in its object space (as flat_cam_o)
     // world boxes of those triangles, grown by 1e-4 of the scene's reach (rt_api.hip set_inline_boxes): a triangle whose box
     // no ray of the wave meets is not tested, and a wave that meets none of them does not prepare its rays for the instance
     float inl_box[RT_INLINE_MAX_TRIS][6];
@@ -300,7 +301,7 @@ RT_DEV int node_step(const RT_GLOBAL PackedNode* nodes, const BoxRay& r, int cur
 // The box test is a plain slab test in world space with the hardware reciprocal: the boxes are grown far beyond its
 // rounding (1e-4 of the scene's reach against ~1e-7 of the coordinates) and the comparison has a relative slack of 1e-5 on
 // top, so a ray that the triangle test would accept is never turned away; which triangles get tested changes no result.
-template <bool COUNT>
+template <bool COUNT, bool CAMERA_ORIGIN = false>
 RT_DEV void inlined_triangles_first(const SceneView& sc, f3 o, f3 d, float tmin, int inst, ClosestHit& best, TraverseCounters& cnt) {
     u32 need = 0; // bit j: some ray of the wave meets the box of triangle j (wave-uniform)
     {
@@ -320,7 +321,8 @@ RT_DEV void inlined_triangles_first(const SceneView& sc, f3 o, f3 d, float tmin,
         }
     }
     if (need == 0u) return;
-    const RayPrep irp = prepare_ray<true>(xform_point43(sc.inl_w2o, o), xform_dir43(sc.inl_w2o, d));
+    const f3 oo = CAMERA_ORIGIN ? mk3(sc.inl_cam_o[0], sc.inl_cam_o[1], sc.inl_cam_o[2]) : xform_point43(sc.inl_w2o, o);
+    const RayPrep irp = prepare_ray<true>(oo, xform_dir43(sc.inl_w2o, d));
     const RT_GLOBAL TriRec* tr = (const RT_GLOBAL TriRec*) ((const RT_GLOBAL char*) sc.inl_tris + (size_t) ((u32) irp.kz * sc.inl_copy_bytes));
     for (u32 j = 0; j < sc.inl_count; j++) {
         if (!((need >> j) & 1u)) continue;
@@ -416,7 +418,7 @@ RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, 
     // ~95 vector instructions each) only for the instances that one of its rays enters -- a wave of sky or floor pixels skips
     // one or both.  The step is the one the loop would have taken first: same stack, same order, same counters.
     static_assert(!INL || K == 1, "the inlined instance goes with a tree of one instance");
-    if (INL && cur != RT_TRAVERSAL_DONE) inlined_triangles_first<COUNT>(sc, o, d, tmin, sc.flat_inl_inst, best, cnt); // (SceneView::flat_inl_inst)
+    if (INL && cur != RT_TRAVERSAL_DONE) inlined_triangles_first<COUNT, CAMERA_ORIGIN>(sc, o, d, tmin, sc.flat_inl_inst, best, cnt); // (SceneView::flat_inl_inst)
     bool enters[2] = { true, true };
     if (K > 1) {
         enters[0] = false; enters[1] = false;
