@@ -70,6 +70,7 @@ struct rt_ctx {
     // flat tree: scenes of at most RT_FLAT_MAX_INSTANCES instances get ONE tree over all instanced triangles besides the two
     // levels (trace_flat, rt_dev_scene.h); flat_instances = 0: none.  RT_FLAT=0 switches it off (tuning aid, two-level tests).
     bool stack_deep_ok = true; // RT_STACK_DEEP=0: deep trees always on the spilling stack (tuning aid)
+    bool flat_waves7 = true; /* RT_FLAT_WAVES7 */
     bool flat_enabled = true, flat_waves8 = true; u32 flat_instances = 0, flat_tris = 0, flat_first1 = 0;
     // inlined instance of the two-level walk (SceneView::inl_inst); RT_INLINE=0 switches it off (tuning aid)
     float sort_chord_pct = 0.5f; /* RT_SORT_CHORD */ int sort_box = 1; float flat_box[RT_FLAT_MAX_INSTANCES][6] = {}; u32 flat_big = 0; // RT_SORT_BOX
@@ -300,6 +301,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     for (int k = 0; k < 3; k++) { const float* m = c->inl_w2o; const float* p = a.camera_origin; a.scene.inl_cam_o[k] = p[0] * m[k] + p[1] * m[3 + k] + p[2] * m[6 + k] + m[9 + k]; } // xform_point43, operation for operation
     a.scene.flat_instances = c->flat_instances;
     a.flat_waves8 = (c->flat_waves8 && c->flat_instances == 1 && c->flat_info.depth + 2 <= 20) ? 1u : 0u;
+    a.flat_waves7 = (c->flat_waves7 && c->flat_instances == 2 && c->flat_info.depth + 2 <= 22) ? 1u : 0u; // the two-instance kernels fit 72 VGPRs since the ray preparation moved behind the root step
     if (c->flat_instances) {
         a.scene.flat_nodes = c->d_flat_nodes; a.scene.flat_tris = c->d_flat_tris; a.scene.flat_copy_bytes = (u32) (c->flat_tris * sizeof(FlatTri));
         for (int k = 0; k < 3; k++) { a.scene.flat_ctr[k] = c->flat_info.ctr[k]; a.scene.flat_inv_h[k] = c->flat_info.inv_h[k]; }
@@ -659,6 +661,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_FLAT")) c->flat_enabled = atoi(v) != 0;
     if (const char* v = getenv("RT_STACK_DEEP")) c->stack_deep_ok = atoi(v) != 0;
     if (const char* v = getenv("RT_FLAT_WAVES8")) c->flat_waves8 = atoi(v) != 0;
+    if (const char* v = getenv("RT_FLAT_WAVES7")) c->flat_waves7 = atoi(v) != 0;
     if (const char* v = getenv("RT_FRAMES_IN_FLIGHT")) c->frames_in_flight = atoi(v);
     if (const char* v = getenv("RT_EXACT_INSTANCE_BOXES")) c->exact_instance_boxes = atoi(v) != 0;
     hipDeviceProp_t prop;

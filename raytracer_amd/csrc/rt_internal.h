@@ -145,6 +145,7 @@ struct PassArgs {
     u32 lazy_render_target;      // the resolve leaves the render target alone (rt_api.hip derives it from the accumulator when it is read)
     u32 defer_resolve;           // fused camera pass: finished paths leave their pixel's sample sum in ps.sum_* for k_frame_resolve
     u32 stack_in_lds;            // the trees are shallow enough for the LDS rows of the traversal stack alone (LaneStack<false>)
+    u32 flat_waves7;             // two-instance flat tree shallow enough for 22 LDS rows: 7 waves per SIMD (RT_FLAT_WAVES7)
     u32 flat_waves8;             // one-instance flat tree shallow enough for 20 LDS rows: traversal kernels at 8 waves per SIMD
     u32 wave_major;              // queued traverse launches: task -> (segment, wave) mapping, see k_traverse (RT_WAVE_MAJOR)
     float sort_box[6]; float sort_chord; u32 sort_box_on; // k_shade rank_sorted: 1 = rays crossing this world box (the big mesh of a two-instance scene) are queued apart, 2 = by the length of their way through it (the top level's box); RT_SORT_BOX=0: neither

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
     // by registers, 19 per CU by their 8.25 KB of LDS, all of it stack, the side store in registers (LaneStack SIDE_REGS)
     // -- the node step without the clamps and overflow branches of the spilling stack (41 instead of 50 vector instructions)
     constexpr bool DEEP = !PERSISTENT && !SPILL && FLAT == 0 && WAVES_PER_SIMD == 5;
-    __shared__ int smem[(DEEP ? 33 : WAVES_PER_SIMD == 8 ? 20 : 26) * TRAVERSE_WAVE]; // 8 waves per SIMD = 32 per CU: 5 KB each of the 160 KB
+    __shared__ int smem[(DEEP ? 33 : WAVES_PER_SIMD == 8 ? 20 : WAVES_PER_SIMD == 7 ? 22 : 26) * TRAVERSE_WAVE]; // 8 waves per SIMD = 32 per CU: 5 KB each of the 160 KB; 7: 28 per CU, 5.5 KB
     typedef LaneStack<SPILL, DEEP> Stack;
     TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
     u32 part = blockIdx.x % TASK_PARTS;
@@ -1038,12 +1038,14 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
         if (primary) {
             if (count_traversal) { if (two) hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
                                    else hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks); }
+            else if (two && a.flat_waves7) hipLaunchKernelGGL((k_traverse<false, 7, true, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
             else if (two) hipLaunchKernelGGL((k_traverse<false, 6, true, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
             else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
             else hipLaunchKernelGGL((k_traverse<false, 6, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
         } else {
             if (count_traversal) { if (two) hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
                                    else hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks); }
+            else if (two && a.flat_waves7) hipLaunchKernelGGL((k_traverse<false, 7, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
             else if (two) hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
             else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
             else hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
