@@ -337,8 +337,10 @@ def main():
         if pmc is not None and args.workload == "c2" and cyc_mix:
             try:
                 ks = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["c2"]["kernels"]
-                per_frame = ["k_traverse<false, 6, true, false, false, 2>", "k_traverse<false, 6, false, false, false, 2>",
-                             "k_shade<true, true>", "k_shade<false, true>", "k_frame_resolve"]
+                def timed_traverse(primary):  # the instantiation the timed frames ran (not the counting one): the most launches
+                    cand = [k for k in ks if k.startswith("k_traverse<false, ") and k.split(", ")[2] == primary]
+                    return max(cand, key=lambda k: ks[k]["launches_sampled"])
+                per_frame = [timed_traverse("true"), timed_traverse("false"), "k_shade<true, true>", "k_shade<false, true>", "k_frame_resolve"]
                 frame_insts = sum(ks[k]["SQ_INSTS_VALU"] for k in per_frame)
                 frame_issue_frac = frame_insts * cyc_mix / (dt_max / args.steps * SIMDS * CLOCK_GHZ * 1e9)
             except (OSError, KeyError, ValueError):
