@@ -313,9 +313,9 @@ RT_DEV void inlined_triangles_first(const SceneView& sc, f3 o, f3 d, float tmin,
                 const float x0 = (b[0] - o.x) * ix, x1 = (b[3] - o.x) * ix;
                 const float y0 = (b[1] - o.y) * iy, y1 = (b[4] - o.y) * iy;
                 const float z0 = (b[2] - o.z) * iz, z1 = (b[5] - o.z) * iz;
-                const float en = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+                const float en = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
                 const float ex = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), best.t));
-                in_box = en * 0.99999f <= ex * 1.00001f;
+                in_box = en <= __builtin_fmaf(1.0e-5f, fabsf(en) + fabsf(ex), ex); // [tmin, closest hit so far] of the ray against the box, with slack
             }
             if (__any(in_box)) need |= 1u << j;
         }
