@@ -57,7 +57,7 @@ template <typename T> void dev_free(T*& p) { if (p) { (void) hipFree(p); p = nul
 struct rt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    LbvhWorkspace lbvh; PlocWorkspace ploc; SahWorkspace sah; int bvh_builder = 4; float sah_tri = 1.3f; // RT_BVH_BUILDER: 0 LBVH, 1 PLOC, 2 binned SAH, 3 SAH for BLAS + PLOC for the TLAS, 4 the cheaper of PLOC and SAH (default); RT_SAH_TRI
+    LbvhWorkspace lbvh; PlocWorkspace ploc; SahWorkspace sah; int bvh_builder = 4; float sah_tri = 0.5f; // RT_BVH_BUILDER: 0 LBVH, 1 PLOC, 2 binned SAH, 3 SAH for BLAS + PLOC for the TLAS, 4 the cheaper of PLOC and SAH (default); RT_SAH_TRI
     bool exact_instance_boxes = true; // RT_EXACT_INSTANCE_BOXES=0: TLAS boxes from the corners of the BLAS box (tuning aid)
     std::vector<Blas> blas;
     std::vector<TranslucentMesh> translucent_meshes;
