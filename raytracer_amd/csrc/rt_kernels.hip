@@ -851,8 +851,16 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
                 auto add = [&](const Term& c) {
                     E.x = __builtin_fmaf(c.bs.x, c.w.x, E.x); E.y = __builtin_fmaf(c.bs.y, c.w.y, E.y); E.z = __builtin_fmaf(c.bs.z, c.w.z, E.z);
                 };
+                // Tabulated profile: beyond its support the filtered value is exactly zero (the table's zero border), and adding
+                // 0 * payload leaves the sum as it is -- four points that lie that far from every hit of the wave are skipped
+                // (the squared distances are the ones the terms start from; the cut is 0.1 % and two texels outside the support;
+                // C4 +1.9 %; testing the points in pairs of two instead: +1 %, the tests cost more than the extra skips save)
+                const float cut = MODE == 1 ? scale * ((float) (a.bssrdf_texels + 2) / (float) a.bssrdf_texels) * 1.001f : 0.0f;
+                const float cut2 = cut * cut;
+                auto dist2 = [&](u32 k) -> float { const const_floats q = pts + 6u * k; f3 dp = mk3(q[0], q[1], q[2]) - hit; return dot3(dp, dp); };
                 u32 k = 0;
                 for (; k + 4 <= nk; k += 4) {
+                    if (MODE == 1 && __all(fminf(fminf(dist2(k), dist2(k + 1)), fminf(dist2(k + 2), dist2(k + 3))) >= cut2)) continue;
                     Term c0 = term(k), c1 = term(k + 1), c2 = term(k + 2), c3 = term(k + 3);
                     add(c0); add(c1); add(c2); add(c3);
                 }
