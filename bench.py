@@ -25,6 +25,8 @@ The JSON line also carries
                 passes against 8 TB/s; `model` keeps SURVEY.md 8(d)'s bytes-per-ray figure (not an HBM ceiling).
   cpu_baseline: the CPU oracle (oracle/, test infrastructure) timed on this host on a bounded sample of the same
                 workload; it also supplies the per-ray node/triangle/instance counts of the bytes-per-ray model.
+
+`preroll_steps`: untimed frames rendered before the W warm-up steps (at least 50 ms of them) so that short runs start at steady clocks.
 """
 import argparse
 import json
@@ -185,6 +187,15 @@ def main():
         distributed.render_frame(rt, scene.globals, step_index[0] if tile else step_index[0] * world + rank, chain)
         step_index[0] += 1
 
+    # steady clocks first: a GPU that has just built the scene is still at idle clocks, and `--warmup 5` frames of C2 are 0.7 ms
+    # (measured: 20 timed steps read 7 % low after 5 warm-up steps, 1 % low after 100).  At least 50 ms of untimed frames
+    # go before the W warm-up steps; their number is reported as `preroll_steps`.
+    preroll_steps, t_pre = 0, time.perf_counter()
+    while time.perf_counter() - t_pre < 0.05:
+        for _ in range(8):
+            step(False)
+        rt.sync()
+        preroll_steps += 8
     for _ in range(args.warmup):
         step(False)
     rt.sync()
@@ -352,7 +363,7 @@ def main():
                       if (args.width, args.height) == (1920, 1080) else "Mrays/s (primary+secondary)",
             "value": total_rays / dt_max / 1e6,
             "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll_steps,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if tile else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
