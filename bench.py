@@ -191,7 +191,7 @@ def main():
     # (measured: 20 timed steps read 7 % low after 5 warm-up steps, 1 % low after 100).  At least 50 ms of untimed frames
     # go before the W warm-up steps; their number is reported as `preroll_steps`.
     preroll_steps, t_pre = 0, time.perf_counter()
-    while time.perf_counter() - t_pre < 0.05:
+    while not args.dump_accumulator and time.perf_counter() - t_pre < 0.05:  # (a dumped image is the W + K frames alone)
         for _ in range(8):
             step(False)
         rt.sync()

@@ -140,6 +140,36 @@ RT_DEV u32 block_rank_keyed(bool pred, u32 key, u32* s_cnt, u32& total) {
     return s_cnt[key * 16u + wave] + below;
 }
 
+// ranking by a key of up to 8 bits through an LDS histogram: one returning LDS atomic per thread (its rank among the threads
+// of its key, in arrival order), a scan of the key counts by wave 0.  s_cnt: [(1 << BITS) + 1] words.  Cheaper than the
+// ballots of block_rank_keyed from 16 keys on (C2 / C5 +0.6 % at equal keys).  The order inside a key varies from run to
+// run; nothing depends on it: a path's arithmetic does not know its queue slot.
+template <int BITS>
+RT_DEV u32 block_rank_hist(bool pred, u32 key, u32* s_cnt, u32& total) {
+    constexpr u32 NK = 1u << BITS, PER = (NK + 63u) / 64u;
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (threadIdx.x < NK) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    u32 r = 0;
+    if (pred) r = atomicAdd(&s_cnt[key], 1u);
+    __syncthreads();
+    if (wave == 0) {
+        u32 c[PER], sum = 0;
+#pragma unroll
+        for (u32 k = 0; k < PER; k++) { const u32 idx = PER * lane + k; c[k] = idx < NK ? s_cnt[idx] : 0u; sum += c[k]; }
+        u32 inc = sum;
+        for (int off = 1; off < 64; off <<= 1) { u32 o = __shfl_up(inc, off); if ((int) lane >= off) inc += o; }
+        u32 run = inc - sum;
+#pragma unroll
+        for (u32 k = 0; k < PER; k++) { const u32 idx = PER * lane + k; if (idx < NK) s_cnt[idx] = run; run += c[k]; }
+        if (lane == 63u) s_cnt[NK] = inc;
+    }
+    __syncthreads();
+    total = s_cnt[NK];
+    return s_cnt[key] + r;
+}
+
 RT_DEV u32 wave_sum(u32 v) {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
     return v;
@@ -460,6 +490,7 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
     f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
     ShadeOut r;
+    int hit_inst = 0;
     f3 thr_prev = mk3(1.0f, 1.0f, 1.0f), rad = mk3(0.0f, 0.0f, 0.0f), thr = mk3(0.0f, 0.0f, 0.0f);
     // the last bounce in the fused pass: every path ends here and only the emission of what it hit still counts -- the
     // ray origin and (shade_ray) the scattering of Lambert surfaces are not needed, nor the RNG state unless the pixel
@@ -512,6 +543,7 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         }
         h.prim_global = 0;
         float payload_t = a.probe ? inf_f32() : (float) bounce; // raytracing.hlsl:102-107
+        hit_inst = h.inst;
         shade_ray(a.shade, a.g, a.fudge, o, d, h, payload_t, rng, r, tail);
         rad = rad + r.emission * thr_prev;            // :113
         thr = thr_prev * r.reflectance;               // :114
@@ -573,9 +605,13 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
     __shared__ u32 s_cnt[513];
     // rank of a surviving path in the next queue: by (key, thread) when a.ray_sort is set, by thread otherwise
     auto rank_sorted = [&]() -> u32 {
-        if (!a.ray_sort || (!FUSED && !a.sort_box_on)) return block_rank(cont, s_wave, total); // (the octant sort alone does not pay for the scattered stores of the unfused pass: cornell as shipped -2.7 %)
-        const u32 key = (nd.x < 0.0f ? 1u : 0u) | (nd.y < 0.0f ? 2u : 0u) | (nd.z < 0.0f ? 4u : 0u);
-        if (!a.sort_box_on) return block_rank_keyed<3>(cont, key, s_cnt, total);
+        if (!a.ray_sort || (!FUSED && !a.sort_box_on)) return block_rank(cont, s_wave, total); // (a direction sort alone does not pay in the unfused pass: cornell as shipped -2.7 %, scattered stores or not)
+        // direction key: the octant and the dominant axis (24 of 32 values in use).  Rays of one tile that agree in both walk the
+        // tree alike; the dominant axis on top of the octant: C3 +1.2 %, C2 +1.9 % (profiles/r02_ab_sort_box.txt)
+        const float ax = fabsf(nd.x), ay = fabsf(nd.y), az = fabsf(nd.z);
+        const u32 dom = az > fmaxf(ax, ay) ? 2u : (ay > ax ? 1u : 0u);
+        const u32 key = ((nd.x < 0.0f ? 1u : 0u) | (nd.y < 0.0f ? 2u : 0u) | (nd.z < 0.0f ? 4u : 0u)) << 2 | dom;
+        if (!a.sort_box_on) return block_rank_hist<5>(cont, key, s_cnt, total);
         // Two-instance scenes (a mesh in a room, a mesh on a floor): whether the new ray crosses the world box of the instance
         // with the most triangles is a second sort key.  A wave takes as long as its longest ray, and the rays that go for
         // the mesh are the long ones: apart, they leave the other waves short.  (uniform branch)
@@ -589,18 +625,19 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             // Two-level scenes: the box is the top level's, and the key is the length of the ray's way through it, in four classes
             // around a.sort_chord (0.5 % of the box's diagonal: a ray that stays that long among the instances meets several of
             // them), longest first -- queued launches run the waves of a segment in order, and the launch ends with its longest
-            // wave (52,743-instance field: +7.3 % at 1080p with two classes, +8.4 % with four; longest last: -4 %)
+            // wave (52,743-instance field: +7.3 % at 1080p with two classes, +8.4 % with four; longest last: -4 %) -- then two
+            // bits of the instance the ray leaves (rays off the same mesh start alike: +1.3 %), then the octant
             const float ch = ex - en;
             const u32 cls = (ch >= 0.25f * a.sort_chord ? 1u : 0u) + (ch >= a.sort_chord ? 1u : 0u) + (ch >= 4.0f * a.sort_chord ? 1u : 0u);
             if (!FUSED) return block_rank_keyed<3>(cont, 3u - cls, s_cnt, total); // few keys where the stores scatter (below)
-            return block_rank_keyed<5>(cont, key | ((3u - cls) << 3), s_cnt, total);
+            return block_rank_hist<7>(cont, ((3u - cls) << 5) | (((u32) hit_inst & 3u) << 3) | (key >> 2), s_cnt, total);
         }
         const u32 cross = en <= ex ? 1u : 0u;
-        // measured (profiles/r02_ab_sort_box.txt): the fused pass keeps the octants and queues the crossing rays last (C2 +2 %,
+        // measured (profiles/r02_ab_sort_box.txt): the fused pass keeps the direction key and queues the crossing rays last (C2 +2 %,
         // first: +1.2 %); the unfused pass, whose seven stores per ray scatter with the key, does best with this one bit alone,
         // crossing rays first (C4 +8.7 %; last: +5.5 %; with the octants: +3.6 %)
         if (!FUSED) return block_rank_keyed<3>(cont, cross ^ 1u, s_cnt, total);
-        return block_rank_keyed<4>(cont, key | ((a.sort_box_on == 3u ? cross ^ 1u : cross) << 3), s_cnt, total);
+        return block_rank_hist<6>(cont, ((a.sort_box_on == 3u ? cross ^ 1u : cross) << 5) | key, s_cnt, total);
     };
     if (FUSED) {
         // Survivors are compacted to the front of the segment, grouped by the octant of their new direction when
