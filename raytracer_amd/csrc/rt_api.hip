@@ -115,6 +115,7 @@ struct rt_ctx {
     // frames with the sample-point pass or the gather are pipelined too: each lane gathers from its own copy of the sample
     // points (d_sp_read / d_sp_read_alt), the passes that update d_sp_write and the copies out of it run in frame order
     // (probe_done), the rest of a frame beside the frame before.  sp_version counts the updates of d_sp_write.
+    float4 *d_sp_pay = nullptr, *d_sp_pay_alt = nullptr; // payloads of d_sp_read / d_sp_read_alt in Morton order (k_gather)
     RtSamplePoint* d_sp_read_alt = nullptr; hipEvent_t probe_done[2] = { nullptr, nullptr }; int last_probe_lane = -1;
     uint64_t sp_version = 0, sp_read_version[2] = { 0, 0 };
     hipEvent_t accumulate_after = nullptr; // run_pass: the frame's resolve waits for this (the previous frame's end)
@@ -223,6 +224,7 @@ int ensure_second_lane(rt_ctx* c) {
     for (int k = 0; k < 2; k++) if (!c->probe_done[k]) RT_HIP(hipEventCreateWithFlags(&c->probe_done[k], hipEventDisableTiming));
     if (c->n_points && !c->d_sp_read_alt) {
         RT_HIP(hipMalloc(&c->d_sp_read_alt, sizeof(RtSamplePoint) * c->n_points));
+        RT_HIP(hipMalloc(&c->d_sp_pay_alt, sizeof(float4) * c->n_points));
         c->sp_read_version[1] = ~0ull; // filled from d_sp_write by the first frame that gathers from it
     }
     if (c->alt.d_arena) return RT_OK;
@@ -245,7 +247,7 @@ int quiesce(rt_ctx* c) {
 
 void free_sample_points(rt_ctx* c) {
     dev_free(c->d_sp_read); dev_free(c->d_sp_write); dev_free(c->d_sp_normal); dev_free(c->d_sp_slice);
-    dev_free(c->d_sp_read_alt); c->sp_version = 0; c->sp_read_version[0] = 0; c->sp_read_version[1] = ~0ull;
+    dev_free(c->d_sp_read_alt); dev_free(c->d_sp_pay); dev_free(c->d_sp_pay_alt); c->sp_version = 0; c->sp_read_version[0] = 0; c->sp_read_version[1] = ~0ull;
     dev_free(c->d_slices); dev_free(c->d_slot_to_ti);
     dev_free(c->d_hg_nodes); dev_free(c->d_hg_sums); dev_free(c->d_hg_pos); dev_free(c->d_hg_pay); dev_free(c->d_hg_order); dev_free(c->d_hg_slices);
     c->hg_built = false;
@@ -322,6 +324,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.gseg_count = c->d_seg_count + 2 * (size_t) c->n_segments_cap;
     a.goff = c->d_seg_count + 3 * (size_t) c->n_segments_cap;
     a.stack_spill = c->d_stack_spill;
+    a.sp_pay = c->d_sp_pay;
     a.stats = c->d_stats;
     a.capture = nullptr;
     a.accumulator = c->d_accumulator; a.render_target = c->d_render_target;
@@ -1130,6 +1133,9 @@ int hg_build_all(rt_ctx* c) {
     RT_HIP(hipMemset(c->d_hg_pay, 0, sizeof(float4) * c->n_points));
     RT_HIP(hipMemcpy(c->d_hg_order, order.data(), 4 * (size_t) c->n_points, hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(c->d_hg_slices, hs.data(), sizeof(HgSlice) * hs.size(), hipMemcpyHostToDevice));
+    RT_HIP(hipMalloc(&c->d_sp_pay, sizeof(float4) * c->n_points));
+    { int prc = launch_sort_payload(c->stream, c->d_sp_read, c->d_hg_order, c->d_sp_slice, c->d_slices, c->n_points, c->d_sp_pay); if (prc) return prc; }
+    RT_HIP(hipStreamSynchronize(c->stream));
     c->hg_built = true;
     return RT_OK;
 }
@@ -1168,13 +1174,20 @@ int validate_dispatch(rt_ctx* c) {
     return RT_OK;
 }
 
+// the current lane's read copy of the sample points <- d_sp_write (raytracing.cpp:723-728), and their payloads in Morton order
+int refresh_read_points(rt_ctx* c) {
+    RT_HIP(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream));
+    if (c->hg_built && c->d_sp_pay) return launch_sort_payload(c->stream, c->d_sp_write, c->d_hg_order, c->d_sp_slice, c->d_slices, c->n_points, c->d_sp_pay);
+    return RT_OK;
+}
+
 // one frame on c->stream with the context's current set of path buffers, nothing else in flight (the order of
 // raytracing.cpp:652-747)
 int dispatch_serial(rt_ctx* c) {
     const bool collect = (c->flags & RT_FLAG_COLLECT_SAMPLES) && c->n_points > 0;
     int rc = RT_OK;
     if (c->n_points && c->sp_read_version[0] != c->sp_version) { // the last pipelined frame that collected samples ran on lane 1
-        RT_HIP(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream));
+        { int prc = refresh_read_points(c); if (prc) return prc; }
         c->sp_read_version[0] = c->sp_version;
     }
     auto refresh_hg = [&]() -> int { // node sums of the payloads the camera pass is about to read
@@ -1186,7 +1199,7 @@ int dispatch_serial(rt_ctx* c) {
     if (c->flags & RT_FLAG_DOUBLE_DISPATCH) { rc = refresh_hg(); if (rc) return rc; }
     if (c->flags & RT_FLAG_DOUBLE_DISPATCH) { rc = run_pass(c, false); if (rc) return rc; } // :688-695
     if (collect) {
-        RT_HIP(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream)); // :723-728
+        { int prc = refresh_read_points(c); if (prc) return prc; } // :723-728
         c->sp_read_version[0] = ++c->sp_version;
     }
     rc = refresh_hg(); if (rc) return rc;
@@ -1218,14 +1231,14 @@ int rt_dispatch_rays(rt_ctx* c) {
             c->pipelined = true; c->next_lane = 0; c->have_previous = false; c->last_probe_lane = -1;
         }
         const int lane = c->next_lane;
-        auto swap_lane = [&]() { if (lane) { swap_path_buffers(c); std::swap(c->stream, c->alt_stream); std::swap(c->d_sp_read, c->d_sp_read_alt); } };
+        auto swap_lane = [&]() { if (lane) { swap_path_buffers(c); std::swap(c->stream, c->alt_stream); std::swap(c->d_sp_read, c->d_sp_read_alt); std::swap(c->d_sp_pay, c->d_sp_pay_alt); } };
         swap_lane();
         int rc = RT_OK;
         auto hip_ok = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == RT_OK) { set_error("rt_dispatch_rays: %s failed: %s", what, hipGetErrorString(e)); rc = RT_ERR_DEVICE; } };
         if (collect || (gather && c->sp_read_version[lane] != c->sp_version)) {
             if (c->last_probe_lane >= 0 && c->last_probe_lane != lane) hip_ok(hipStreamWaitEvent(c->stream, c->probe_done[c->last_probe_lane], 0), "event wait");
             if (rc == RT_OK && collect) { rc = run_pass(c, true); if (rc == RT_OK) c->sp_version++; } // raytracing.cpp:677-687
-            if (rc == RT_OK) hip_ok(hipMemcpyAsync(c->d_sp_read, c->d_sp_write, sizeof(RtSamplePoint) * c->n_points, hipMemcpyDeviceToDevice, c->stream), "sample point copy"); // :723-728
+            if (rc == RT_OK) rc = refresh_read_points(c); // :723-728
             if (rc == RT_OK) { c->sp_read_version[lane] = c->sp_version; hip_ok(hipEventRecord(c->probe_done[lane], c->stream), "event record"); c->last_probe_lane = lane; }
         }
         if (rc == RT_OK) {

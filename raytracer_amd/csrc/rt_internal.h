@@ -171,6 +171,7 @@ struct PassArgs {
     u32* seg_count[2];           // rays per segment of the two ping-pong queues
     u32* gseg_count;             // gather items per segment
     u32* goff;                   // [n_segments + 1] exclusive scan of gseg_count (k_gather_offsets)
+    const float4* sp_pay;        // payloads of sp_read in the Morton order of the points (k_sort_payload, k_gather)
     int* stack_spill;            // [48][n_paths] overflow of the per-lane traversal stack
     DeviceStats* stats;
     RtHit* capture;              // [(bounces+1) * width*height] or null
@@ -193,6 +194,7 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
 // fused: finished camera paths resolve their pixel in the shade kernel (no launch_camera_resolve afterwards)
 int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index, bool primary, bool fused);
 int launch_gather(hipStream_t s, const PassArgs& a);
+int launch_sort_payload(hipStream_t s, const RtSamplePoint* src, const u32* order, const u32* slice_of, const rtd::TranslucentSlice* slices, u32 n, float4* pay);
 int launch_hg_sums(hipStream_t s, const PassArgs& a, u32 n_slices); // refresh HgView::pay / sums from sp_read
 int launch_camera_resolve(hipStream_t s, const PassArgs& a);
 int launch_frame_resolve(hipStream_t s, const PassArgs& a); // pipelined frames: adds the sample sums the fused shades left in ps.sum_* (a.defer_resolve)

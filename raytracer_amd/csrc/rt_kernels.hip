@@ -762,7 +762,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
     const u32 n_items = a.goff[a.n_segments];
     if (blockIdx.x * GATHER_BLOCK >= n_items) return; // uniform
     const u32 j = blockIdx.x * GATHER_BLOCK + threadIdx.x;
-    const bool active = j < n_items;
+    bool active = j < n_items;
     u32 i;
     {   // item j of the numbering -> its segment (last s with goff[s] <= j) -> its queue slot
         const u32 jj = active ? j : n_items - 1u;
@@ -771,6 +771,40 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
         i = lo * SEG + (jj - a.goff[lo]);
     }
     const GatherQueue& g = a.gq;
+    if (MODE == 1 && a.sort_box_on == 1u) {
+        // The workgroup's items regrouped by the cell of the mesh's box their hit lies in: the hits of a wave then sit
+        // together, and more of the far point groups below are far for the whole wave (the skip needs every lane to agree)
+        __shared__ u32 s_key[66];
+        __shared__ u32 s_perm[GATHER_BLOCK];
+        if (threadIdx.x < 66) s_key[threadIdx.x] = 0u;
+        __syncthreads();
+        u32 key = 64u; // inactive threads last
+        if (active) { // 4 x 4 x 4 cells of the mesh's box, numbered along the Morton curve
+            const float h[3] = { g.hx[i], g.hy[i], g.hz[i] };
+            u32 q[3];
+            for (int k = 0; k < 3; k++) {
+                const float t = (h[k] - a.sort_box[k]) * fast_rcp(a.sort_box[3 + k] - a.sort_box[k]) * 4.0f;
+                q[k] = (u32) fminf(fmaxf(t, 0.0f), 3.0f);
+            }
+            key = 0u;
+            for (int k = 0; k < 3; k++) key |= ((q[k] & 1u) << k) | ((q[k] & 2u) << (k + 2));
+        }
+        const u32 r = atomicAdd(&s_key[key], 1u);
+        __syncthreads();
+        if (threadIdx.x < 64) { // exclusive scan of the 64 cell counts by the first wave; [65] = all of them = the number of items
+            const u32 c = s_key[threadIdx.x];
+            u32 inc = c;
+            for (int off = 1; off < 64; off <<= 1) { u32 o = __shfl_up(inc, off); if ((int) threadIdx.x >= off) inc += o; }
+            s_key[threadIdx.x] = inc - c;
+            if (threadIdx.x == 63) s_key[65] = inc;
+        }
+        __syncthreads();
+        const u32 n_active = s_key[65];
+        s_perm[(key < 64u ? s_key[key] : n_active) + r] = i;
+        __syncthreads();
+        i = s_perm[threadIdx.x];
+        active = threadIdx.x < n_active;
+    }
     const f3 hit = mk3(g.hx[i], g.hy[i], g.hz[i]);
     const int my_ti = active ? g.ti[i] : -1;
     const float scale = a.g.translucent_bssrdf_scale;
@@ -861,7 +895,12 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
             const int cur_u = __builtin_amdgcn_readfirstlane(cur);
             const TranslucentSlice sl = a.shade.slices[cur_u];
             typedef const __attribute__((address_space(4))) float* const_floats;
-            const const_floats pts = (const_floats) (unsigned long long) (a.sp_read + sl.offset); // 6 floats per point (RtSamplePoint)
+            // the points are walked in Morton order of their positions (the hierarchical gather's `pos` and `order`, built with
+            // every set of sample points: rt_api.hip hg_build_all): neighbours in the walk are neighbours in space, which is what
+            // makes whole groups of them far from a wave's hits (the skip below).  The sum runs in that order -- a fixed order,
+            // other than the reference's index order by rounding only (1e-7, under the radiance tolerance).
+            const const_floats spos = (const_floats) (unsigned long long) (a.hg.pos + sl.offset);     // float4 per point, sorted
+            const const_floats spay = (const_floats) (unsigned long long) (a.sp_pay + sl.offset);    // their payloads, sorted alike (k_sort_payload)
             const u32 nk = sl.count;
             if (my_ti != cur_u) continue;
             // four points per trip: their sqrt / divide chains are independent and overlap; the sum stays in index order.
@@ -871,8 +910,8 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
                 constexpr bool GREY = decltype(grey_tag)::value;
                 struct Term { f3 bs, w; };
                 auto term = [&](u32 k) -> Term {
-                    const const_floats q = pts + 6u * k;
-                    f3 dp = mk3(q[0], q[1], q[2]) - hit;
+                    const const_floats sp = spos + 4u * k, q = spay + 4u * k;
+                    f3 dp = mk3(sp[0], sp[1], sp[2]) - hit;
                     float radius = MODE != 0 ? sqrt_refined(dot3(dp, dp))
                                              : fast_sqrt(__builtin_fmaf(dp.z, dp.z, __builtin_fmaf(dp.y, dp.y, dp.x * dp.x)));
                     f3 bs;
@@ -882,7 +921,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
                                        : fudge_over_z * sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, coord);
                     } else if (GREY) { float v = dipole_eval_fast(cr, radius); bs = mk3(v, v, v); }               // :278-301
                     else bs = mk3(dipole_eval_fast(cr, radius), dipole_eval_fast(cg, radius), dipole_eval_fast(cb, radius));
-                    return Term{bs, mk3(q[3], q[4], q[5])};
+                    return Term{bs, mk3(q[0], q[1], q[2])};
                 };
                 // the sum runs in index order, one fused multiply-add per channel and pair
                 auto add = [&](const Term& c) {
@@ -894,7 +933,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
                 // C4 +1.9 %; testing the points in pairs of two instead: +1 %, the tests cost more than the extra skips save)
                 const float cut = MODE == 1 ? scale * ((float) (a.bssrdf_texels + 2) / (float) a.bssrdf_texels) * 1.001f : 0.0f;
                 const float cut2 = cut * cut;
-                auto dist2 = [&](u32 k) -> float { const const_floats q = pts + 6u * k; f3 dp = mk3(q[0], q[1], q[2]) - hit; return dot3(dp, dp); };
+                auto dist2 = [&](u32 k) -> float { const const_floats sp = spos + 4u * k; f3 dp = mk3(sp[0], sp[1], sp[2]) - hit; return dot3(dp, dp); };
                 u32 k = 0;
                 for (; k + 4 <= nk; k += 4) {
                     if (MODE == 1 && __all(fminf(fminf(dist2(k), dist2(k + 1)), fminf(dist2(k + 2), dist2(k + 3))) >= cut2)) continue;
@@ -916,6 +955,22 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
     }
     pairs = wave_sum(active ? pairs : 0u);
     if ((threadIdx.x & 63u) == 0 && pairs) atomicAdd(&a.stats->gather_pairs, (unsigned long long) pairs);
+}
+
+// payloads of the sample points in the Morton order of their positions (HgView::order), for k_gather's walk: run whenever
+// the read copy of the points is refreshed (rt_api.hip refresh_read_points)
+__global__ __launch_bounds__(BT) void k_sort_payload(const RtSamplePoint* __restrict__ src, const u32* __restrict__ order, const u32* __restrict__ slice_of,
+                                                    const TranslucentSlice* __restrict__ slices, u32 n, float4* __restrict__ pay) {
+    const u32 j = blockIdx.x * BT + threadIdx.x;
+    if (j >= n) return;
+    const RtSamplePoint& p = src[slices[slice_of[j]].offset + order[j]];
+    pay[j] = make_float4(p.payload[0], p.payload[1], p.payload[2], 0.0f);
+}
+int launch_sort_payload(hipStream_t s, const RtSamplePoint* src, const u32* order, const u32* slice_of, const TranslucentSlice* slices, u32 n, float4* pay) {
+    if (!n) return RT_OK;
+    hipLaunchKernelGGL(k_sort_payload, dim3((n + BT - 1) / BT), dim3(BT), 0, s, src, order, slice_of, slices, n, pay);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
 }
 
 // ---- hierarchical gather (rt_set_gather_mode) ----------------------------------------
