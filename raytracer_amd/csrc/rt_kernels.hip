@@ -691,7 +691,8 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
 }
 
 // ---- translucent_chit: sum of bssrdf(|p_i - hit|) * payload_i over all sample points (raytracing.hlsl:321-333) -------
-// One hit per lane, every lane walks all points of its instance in index order (the order of the float sum is part of
+// One hit per lane, every lane walks all points of its instance in one fixed order -- index order for the dipole, Morton order of
+// the positions for the tabulated profile (below) -- (the order of the float sum is part of
 // the result).  The points are the same for all lanes of a wave and arrive through the scalar cache (k_gather); the
 // tabulated profile sits in LDS as one float4 per texel, so the two texel fetches of the linear filter are LDS gathers --
 // reading both from global memory had the texture-address unit as the bottleneck (12 divergent loads per pair).  Hits
@@ -903,7 +904,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
             const const_floats spay = (const_floats) (unsigned long long) (a.sp_pay + sl.offset);    // their payloads, sorted alike (k_sort_payload)
             const u32 nk = sl.count;
             if (my_ti != cur_u) continue;
-            // four points per trip: their sqrt / divide chains are independent and overlap; the sum stays in index order.
+            // four points per trip: their sqrt / divide chains are independent and overlap; the sum stays in the order of the walk.
             // `GREY` is a compile-time flag of the loop (two copies): a branch on it between the four terms would keep
             // the scheduler from interleaving their chains.
             auto run = [&](auto grey_tag) {
@@ -923,7 +924,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
                     else bs = mk3(dipole_eval_fast(cr, radius), dipole_eval_fast(cg, radius), dipole_eval_fast(cb, radius));
                     return Term{bs, mk3(q[0], q[1], q[2])};
                 };
-                // the sum runs in index order, one fused multiply-add per channel and pair
+                // the sum runs in the order of the walk, one fused multiply-add per channel and pair
                 auto add = [&](const Term& c) {
                     E.x = __builtin_fmaf(c.bs.x, c.w.x, E.x); E.y = __builtin_fmaf(c.bs.y, c.w.y, E.y); E.z = __builtin_fmaf(c.bs.z, c.w.z, E.z);
                 };
