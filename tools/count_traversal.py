@@ -5,7 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd import api, scenes, distributed, _abi
 print('RT_SAH_TRI', os.environ.get('RT_SAH_TRI'), 'RT_BVH_BUILDER', os.environ.get('RT_BVH_BUILDER'))
 ALL = {"c2": lambda: scenes.bunny(1920, 1080, 1, 1), "c3": lambda: scenes.cornell(1920, 1080, 2, 4),
-       "c4": lambda: scenes.cornell_bunny(1920, 1080, 1, 4), "c5": lambda: scenes.bunny_field(1920, 1080, 1, 4)}
+       "c4": lambda: scenes.cornell_bunny(1920, 1080, 1, 4), "c5": lambda: scenes.bunny_field(1920, 1080, 1, 4),
+       # the primary launches alone (no bounce), and C5 at its benchmark size
+       "c2p": lambda: scenes.bunny(1920, 1080, 1, 0), "c5p": lambda: scenes.bunny_field(1920, 1080, 1, 0),
+       "c5p4k": lambda: scenes.bunny_field(3840, 2160, 1, 0), "c5_4k": lambda: scenes.bunny_field(3840, 2160, 1, 4)}
 for name in (sys.argv[1:] or ["c2", "c3", "c4"]):
     sc = ALL[name]()
     rt = api.Raytracer(0); sc.setup(rt, _abi.RT_FLAG_COUNT_TRAVERSAL)
