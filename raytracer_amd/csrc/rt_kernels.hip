@@ -612,9 +612,9 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         const u32 dom = az > fmaxf(ax, ay) ? 2u : (ay > ax ? 1u : 0u);
         const u32 key = ((nd.x < 0.0f ? 1u : 0u) | (nd.y < 0.0f ? 2u : 0u) | (nd.z < 0.0f ? 4u : 0u)) << 2 | dom;
         if (!a.sort_box_on) return block_rank_hist<5>(cont, key, s_cnt, total);
-        // Two-instance scenes (a mesh in a room, a mesh on a floor): whether the new ray crosses the world box of the instance
-        // with the most triangles is a second sort key.  A wave takes as long as its longest ray, and the rays that go for
-        // the mesh are the long ones: apart, they leave the other waves short.  (uniform branch)
+        // Two-instance scenes (a mesh in a room, a mesh on a floor): how far the new ray goes through the world box of the
+        // instance with the most triangles is a second sort key.  A wave takes as long as its longest ray, and the rays that
+        // go through the mesh are the long ones: apart, they leave the other waves short.  (uniform branch)
         const float ix = fast_rcp(nd.x), iy = fast_rcp(nd.y), iz = fast_rcp(nd.z);
         const float x0 = (a.sort_box[0] - no.x) * ix, x1 = (a.sort_box[3] - no.x) * ix;
         const float y0 = (a.sort_box[1] - no.y) * iy, y1 = (a.sort_box[4] - no.y) * iy;
@@ -622,22 +622,33 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         const float en = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
         const float ex = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
         if (a.sort_box_on == 2u) {
-            // Two-level scenes: the box is the top level's, and the key is the length of the ray's way through it, in four classes
-            // around a.sort_chord (0.5 % of the box's diagonal: a ray that stays that long among the instances meets several of
-            // them), longest first -- queued launches run the waves of a segment in order, and the launch ends with its longest
-            // wave (52,743-instance field: +7.3 % at 1080p with two classes, +8.4 % with four; longest last: -4 %) -- then two
-            // bits of the instance the ray leaves (rays off the same mesh start alike: +1.3 %), then the octant
+            // Two-level scenes: the box is the top level's, and the key is the length of the ray's way through it, in eight classes
+            // an octave apart around a.sort_chord (0.5 % of the box's diagonal: a ray that stays that long among the instances
+            // meets several of them), longest first -- queued launches run the waves of a segment in order, and the launch ends
+            // with its longest wave (52,743-instance field: +7.3 % at 1080p with two classes, +8.4 % with four, +1 % more with
+            // eight, the same with sixteen; longest last: -4 %) -- then three bits of the instance the ray leaves (rays off the
+            // same mesh start alike: +1.3 % with two bits, +0.6 % more with three, less again with four; the dominant axis
+            // beside the octant: nothing), then the octant.  The unfused pass: four classes two octaves apart, nothing else
             const float ch = ex - en;
-            const u32 cls = (ch >= 0.25f * a.sort_chord ? 1u : 0u) + (ch >= a.sort_chord ? 1u : 0u) + (ch >= 4.0f * a.sort_chord ? 1u : 0u);
-            if (!FUSED) return block_rank_keyed<3>(cont, 3u - cls, s_cnt, total); // few keys where the stores scatter (below)
-            return block_rank_hist<7>(cont, ((3u - cls) << 5) | (((u32) hit_inst & 3u) << 3) | (key >> 2), s_cnt, total);
+            if (!FUSED) { // few keys where the stores scatter (below)
+                const u32 cls = (ch >= 0.25f * a.sort_chord ? 1u : 0u) + (ch >= a.sort_chord ? 1u : 0u) + (ch >= 4.0f * a.sort_chord ? 1u : 0u);
+                return block_rank_keyed<3>(cont, 3u - cls, s_cnt, total);
+            }
+            u32 c8 = 0;
+            for (int k = -3; k <= 3; k++) c8 += ch >= ldexpf(a.sort_chord, k) ? 1u : 0u;
+            return block_rank_hist<9>(cont, ((7u - c8) << 6) | (((u32) hit_inst & 7u) << 3) | (key >> 2), s_cnt, total);
         }
-        const u32 cross = en <= ex ? 1u : 0u;
-        // measured (profiles/r02_ab_sort_box.txt): the fused pass keeps the direction key and queues the crossing rays last (C2 +2 %,
-        // first: +1.2 %); the unfused pass, whose seven stores per ray scatter with the key, does best with this one bit alone,
-        // crossing rays first (C4 +8.7 %; last: +5.5 %; with the octants: +3.6 %)
-        if (!FUSED) return block_rank_keyed<3>(cont, cross ^ 1u, s_cnt, total);
-        return block_rank_hist<6>(cont, ((a.sort_box_on == 3u ? cross ^ 1u : cross) << 5) | key, s_cnt, total);
+        // Flat scenes of two instances: eight classes, longest way through the mesh's box first (seven equal steps of the box's
+        // diagonal), the rays that miss the box last.  Measured (profiles/r02_ab_sort_box.txt): with one bit (crosses or not)
+        // the fused pass did best with the crossing rays last (C2 +2 %, first: +1.2 %) and the unfused pass, whose seven
+        // stores per ray scatter with the key, with that bit alone, crossing first (C4 +8.7 %; with the octants: +3.6 %);
+        // the eight classes on top of that: C2 +4.8 % (its queued launches 12.7 -> 15.0 Grays/s), C4 +1 % (traversal +4 %);
+        // sixteen classes: the same; without the dominant axis in the direction key: -1 %
+        const float bx = a.sort_box[3] - a.sort_box[0], by = a.sort_box[4] - a.sort_box[1], bz = a.sort_box[5] - a.sort_box[2];
+        const float per_diag = 7.0f * __builtin_amdgcn_rsqf(__builtin_fmaf(bx, bx, __builtin_fmaf(by, by, bz * bz))); // uniform
+        const u32 cls = en <= ex ? 6u - (u32) fminf((ex - en) * per_diag, 6.0f) : 7u; // nd is a unit vector: ex - en is a length
+        if (!FUSED) return block_rank_keyed<3>(cont, cls, s_cnt, total);
+        return block_rank_hist<8>(cont, (cls << 5) | key, s_cnt, total);
     };
     if (FUSED) {
         // Survivors are compacted to the front of the segment, grouped by the octant of their new direction when
