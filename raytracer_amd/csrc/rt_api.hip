@@ -260,7 +260,7 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.ray_sort = c->ray_sort ? 1u : 0u;
     a.wave_major = c->wave_major ? 1u : 0u;
     a.xcd_bands = c->xcd_bands ? 1u : 0u;
-    a.sort_box_on = (c->sort_box && (c->flat_instances == 2u || (c->flat_instances == 1u && c->flat_inl_inst >= 0))) ? 1u : 0u;
+    a.sort_box_on = (c->sort_box && c->flat_instances != 0u) ? 1u : 0u; // flat scenes: the box of the instance with the most triangles (of the only one: the scene's)
     memcpy(a.sort_box, c->flat_box[c->flat_big], sizeof a.sort_box);
     a.sort_chord = 0.0f;
     if (c->sort_box && c->sort_chord_pct > 0.0f && c->flat_instances == 0u && c->n_instances > 0u) {

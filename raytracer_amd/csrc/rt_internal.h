@@ -148,7 +148,7 @@ struct PassArgs {
     u32 flat_waves7;             // two-instance flat tree shallow enough for 22 LDS rows: 7 waves per SIMD (RT_FLAT_WAVES7)
     u32 flat_waves8;             // one-instance flat tree shallow enough for 20 LDS rows: traversal kernels at 8 waves per SIMD
     u32 wave_major;              // queued traverse launches: task -> (segment, wave) mapping, see k_traverse (RT_WAVE_MAJOR)
-    float sort_box[6]; float sort_chord; u32 sort_box_on; // k_shade rank_sorted: new rays are queued by the length of their way through this world box, longest first: 1 = the big mesh's box of a two-instance scene (classes of its diagonal), 2 = the top level's box (classes around sort_chord); RT_SORT_BOX=0: neither
+    float sort_box[6]; float sort_chord; u32 sort_box_on; // k_shade rank_sorted: new rays are queued by the length of their way through this world box, longest first: 1 = flat scenes, the box of the instance with the most triangles (classes of its diagonal), 2 = the top level's box (classes around sort_chord); RT_SORT_BOX=0: neither
     float inv_size[2];           // 1 / width, 1 / height (IEEE quotients of the host: camera_ray)
     u32 xcd_bands;               // traverse launches: the workgroups of one XCD take neighbouring tiles / segments, see k_traverse (RT_XCD_BANDS)
     u32 ray_sort;                // fused camera pass: survivors of a bounce are grouped by direction octant inside their segment (RT_RAY_SORT)

@@ -612,9 +612,9 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         const u32 dom = az > fmaxf(ax, ay) ? 2u : (ay > ax ? 1u : 0u);
         const u32 key = ((nd.x < 0.0f ? 1u : 0u) | (nd.y < 0.0f ? 2u : 0u) | (nd.z < 0.0f ? 4u : 0u)) << 2 | dom;
         if (!a.sort_box_on) return block_rank_hist<5>(cont, key, s_cnt, total);
-        // Two-instance scenes (a mesh in a room, a mesh on a floor): how far the new ray goes through the world box of the
-        // instance with the most triangles is a second sort key.  A wave takes as long as its longest ray, and the rays that
-        // go through the mesh are the long ones: apart, they leave the other waves short.  (uniform branch)
+        // Flat scenes (a mesh in a room, a mesh on a floor, one mesh alone): how far the new ray goes through the world box of
+        // the instance with the most triangles is a second sort key.  A wave takes as long as its longest ray, and the rays
+        // that go through the mesh are the long ones: apart, they leave the other waves short.  (uniform branch)
         const float ix = fast_rcp(nd.x), iy = fast_rcp(nd.y), iz = fast_rcp(nd.z);
         const float x0 = (a.sort_box[0] - no.x) * ix, x1 = (a.sort_box[3] - no.x) * ix;
         const float y0 = (a.sort_box[1] - no.y) * iy, y1 = (a.sort_box[4] - no.y) * iy;
@@ -630,12 +630,9 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             // same mesh start alike: +1.3 % with two bits, +0.6 % more with three, less again with four; the dominant axis
             // beside the octant: nothing), then the octant.  The unfused pass: four classes two octaves apart, nothing else
             const float ch = ex - en;
-            if (!FUSED) { // few keys where the stores scatter (below)
-                const u32 cls = (ch >= 0.25f * a.sort_chord ? 1u : 0u) + (ch >= a.sort_chord ? 1u : 0u) + (ch >= 4.0f * a.sort_chord ? 1u : 0u);
-                return block_rank_keyed<3>(cont, 3u - cls, s_cnt, total);
-            }
             u32 c8 = 0;
             for (int k = -3; k <= 3; k++) c8 += ch >= ldexpf(a.sort_chord, k) ? 1u : 0u;
+            if (!FUSED) return block_rank_keyed<3>(cont, (7u - c8) >> 1, s_cnt, total); // four classes where the stores scatter (below); eight: no difference (Cornell as shipped)
             return block_rank_hist<9>(cont, ((7u - c8) << 6) | (((u32) hit_inst & 7u) << 3) | (key >> 2), s_cnt, total);
         }
         // Flat scenes of two instances: eight classes, longest way through the mesh's box first (seven equal steps of the box's
@@ -643,7 +640,8 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         // the fused pass did best with the crossing rays last (C2 +2 %, first: +1.2 %) and the unfused pass, whose seven
         // stores per ray scatter with the key, with that bit alone, crossing first (C4 +8.7 %; with the octants: +3.6 %);
         // the eight classes on top of that: C2 +4.8 % (its queued launches 12.7 -> 15.0 Grays/s), C4 +1 % (traversal +4 %);
-        // sixteen classes: the same; without the dominant axis in the direction key: -1 %
+        // sixteen classes: the same; without the dominant axis in the direction key: -1 %.  One-instance scenes: the box is the
+        // scene's, the way through it is how far the ray can go at all (C3 +2.2 %, its queued launches 12.7 -> 13.5 Grays/s)
         const float bx = a.sort_box[3] - a.sort_box[0], by = a.sort_box[4] - a.sort_box[1], bz = a.sort_box[5] - a.sort_box[2];
         const float per_diag = 7.0f * __builtin_amdgcn_rsqf(__builtin_fmaf(bx, bx, __builtin_fmaf(by, by, bz * bz))); // uniform
         const u32 cls = en <= ex ? 6u - (u32) fminf((ex - en) * per_diag, 6.0f) : 7u; // nd is a unit vector: ex - en is a length

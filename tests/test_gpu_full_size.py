@@ -119,11 +119,12 @@ def test_frames_in_flight_do_not_change_the_image(monkeypatch):
 def test_scheduling_switches_do_not_change_the_image(monkeypatch):
     """Where a ray sits in its queue, which XCD traces its tile, whether the floor is inlined or the tree flat: none of it may
     change a bit of the image.  Production path (no hit tap, frames in flight), five frames each: the bunny on its floor
-    and Cornell + translucent bunny (two-instance flat scenes: RT_SORT_BOX's crossing key, fused and unfused shade), the
+    and Cornell + translucent bunny (two-instance flat scenes: RT_SORT_BOX's chord classes, fused and unfused shade), the
+    Cornell box alone (one instance: classes of the way through the scene's box), the
     instance field (two levels: chord classes, inlined floor) -- every switch off, one at a time, against all defaults."""
     from raytracer_amd import api, distributed
     cases = [scenes.bunny(960, 540, spp=2, bounces=3), scenes.cornell_bunny(480, 270, spp=2, bounces=3),
-             scenes.bunny_field(640, 360, spp=1, bounces=3, grid=24, count=500)]
+             scenes.bunny_field(640, 360, spp=1, bounces=3, grid=24, count=500), scenes.cornell(480, 270, spp=2, bounces=3)]
     switches = [None, "RT_SORT_BOX", "RT_RAY_SORT", "RT_XCD_BANDS", "RT_INLINE", "RT_FLAT_INLINE", "RT_FLAT", "RT_WAVE_MAJOR"]
     images = {}
     for sw in switches:
