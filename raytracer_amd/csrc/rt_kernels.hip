@@ -602,7 +602,7 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         if (threadIdx.x == 0) a.seg_count[inq ^ 1u][blockIdx.x] = 0u;
         return;
     }
-    __shared__ u32 s_cnt[513];
+    __shared__ u32 s_cnt[1025]; // up to 10 key bits (block_rank_hist)
     // rank of a surviving path in the next queue: by (key, thread) when a.ray_sort is set, by thread otherwise
     auto rank_sorted = [&]() -> u32 {
         if (!a.ray_sort || (!FUSED && !a.sort_box_on)) return block_rank(cont, s_wave, total); // (a direction sort alone does not pay in the unfused pass: cornell as shipped -2.7 %, scattered stores or not)
@@ -628,19 +628,21 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             // with its longest wave (52,743-instance field: +7.3 % at 1080p with two classes, +8.4 % with four, +1 % more with
             // eight, the same with sixteen; longest last: -4 %) -- then three bits of the instance the ray leaves (rays off the
             // same mesh start alike: +1.3 % with two bits, +0.6 % more with three, less again with four; the dominant axis
-            // beside the octant: nothing), then the octant.  The unfused pass: four classes two octaves apart, nothing else
+            // beside the octant: nothing; a bit in front of them for the rays that leave the inlined instance), then the octant.
+            // The unfused pass: four classes two octaves apart, nothing else
             const float ch = ex - en;
             u32 c8 = 0;
             for (int k = -3; k <= 3; k++) c8 += ch >= ldexpf(a.sort_chord, k) ? 1u : 0u;
             if (!FUSED) return block_rank_keyed<3>(cont, (7u - c8) >> 1, s_cnt, total); // four classes where the stores scatter (below); eight: no difference (Cornell as shipped)
-            return block_rank_hist<9>(cont, ((7u - c8) << 6) | (((u32) hit_inst & 7u) << 3) | (key >> 2), s_cnt, total);
+            const u32 inl = hit_inst == a.scene.inl_inst ? 1u : 0u; // off the inlined instance (the floor): no box around the origin to enter first (+1.3 %; as the first key: -2 %)
+            return block_rank_hist<10>(cont, ((7u - c8) << 7) | (inl << 6) | (((u32) hit_inst & 7u) << 3) | (key >> 2), s_cnt, total);
         }
         // Flat scenes of two instances: eight classes, longest way through the mesh's box first (seven equal steps of the box's
         // diagonal), the rays that miss the box last.  Measured (profiles/r02_ab_sort_box.txt): with one bit (crosses or not)
         // the fused pass did best with the crossing rays last (C2 +2 %, first: +1.2 %) and the unfused pass, whose seven
         // stores per ray scatter with the key, with that bit alone, crossing first (C4 +8.7 %; with the octants: +3.6 %);
         // the eight classes on top of that: C2 +4.8 % (its queued launches 12.7 -> 15.0 Grays/s), C4 +1 % (traversal +4 %);
-        // sixteen classes: the same; without the dominant axis in the direction key: -1 %.  One-instance scenes: the box is the
+        // sixteen classes: the same; without the dominant axis in the direction key: -1 %; a bit for the instance the ray leaves: nothing.  One-instance scenes: the box is the
         // scene's, the way through it is how far the ray can go at all (C3 +2.2 %, its queued launches 12.7 -> 13.5 Grays/s)
         const float bx = a.sort_box[3] - a.sort_box[0], by = a.sort_box[4] - a.sort_box[1], bz = a.sort_box[5] - a.sort_box[2];
         const float per_diag = 7.0f * __builtin_amdgcn_rsqf(__builtin_fmaf(bx, bx, __builtin_fmaf(by, by, bz * bz))); // uniform
