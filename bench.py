@@ -36,6 +36,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(1, os.path.join(ROOT, "tools"))
+import pmc_summary  # noqa: E402  (source_hash: which kernel sources a committed PMC entry belongs to)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 SIMDS = 1024           # 256 CUs x 4 SIMDs
@@ -65,6 +67,11 @@ class _DevBuf(object):
     def __init__(self, ptr, nfloats):
         self.__cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 3,
                                          "strides": None}
+
+
+def pmc_key(args):
+    """entry of profiles/pmc_traffic.json for this command: the workload, with the size unless it is 1080p"""
+    return args.workload if (args.width, args.height) == (1920, 1080) else "%s_%dx%d" % (args.workload, args.width, args.height)
 
 
 def build_scene(name, args):
@@ -221,28 +228,53 @@ def main():
         torch.cuda.synchronize()
         rt.sync()
 
+    # The contract times exactly K steps between two fences.  K steps of C2 are 2.6 ms at the driver's K = 20: one stray
+    # clock dip moves such a window by several per cent, so when a block of K steps is shorter than 50 ms, R blocks of K
+    # steps are timed one after the other, each between its own fences, and the MEDIAN block is reported
+    # (`timed_blocks` = R, `block_ms` = all of them; `steps` stays K).
+    def timed_block():
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        rt.sync()
+        fence()
+        d = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(d, op=dist.ReduceOp.MAX)     # the slowest rank's block (outside the timed window)
+        return float(d.item())
+
+    block_s = [timed_block()]
+    if not args.dump_accumulator and block_s[0] < 0.05:
+        for _ in range(min(int(0.05 / max(block_s[0], 1e-6)), 63)):
+            block_s.append(timed_block())
+    dt_block = sorted(block_s)[len(block_s) // 2] if len(block_s) > 1 else block_s[0]
+    # the one exchange step of the job, after its last frame: timed between fences of its own and ADDED to the block
     fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    rt.sync()
-    t_render = time.perf_counter()
+    t_x = time.perf_counter()
+    exchange_bytes = 0
     if dist is not None:
-        if args.rehearse:
+        if tile:
+            # tile split: every rank sends the tiles it owns (1 / N of the frame) straight to rank 0
+            exchange_bytes = distributed.gather_tiles(rt, dist, rank, world, torch.device("cuda", local_rank), dst=0, via_host=args.rehearse)
+        elif args.rehearse:
             dist.all_reduce(acc, op=dist.ReduceOp.SUM)  # gloo has no GPU reduce
+            exchange_bytes = acc.numel() * 4
         else:
-            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)   # RCCL over xGMI: combine the float accumulation buffers
+            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)   # RCCL over xGMI: sum of the float accumulation buffers
+            exchange_bytes = acc.numel() * 4
     fence()
-    dt = time.perf_counter() - t0
-    reduce_ms = (time.perf_counter() - t_render) * 1e3 if dist is not None else 0.0   # this rank's wait for the slowest rank included
+    reduce_ms = (time.perf_counter() - t_x) * 1e3 if dist is not None else 0.0   # this rank's wait for the slowest rank included
+    dt = dt_block + reduce_ms * 1e-3
     if args.dump_accumulator and rank == 0:
         import numpy as np
         np.save(args.dump_accumulator, acc.cpu().numpy().reshape(args.height, args.width, 4))
 
     stats = rt.get_stats()
-    rays = stats["rays_camera"] + stats["rays_probe"]
+    n_blocks = len(block_s)
+    rays = (stats["rays_camera"] + stats["rays_probe"]) / n_blocks         # per block of K steps (the blocks are statistically alike)
     # the tile split replicates the (small) sample-point pass on every rank: those rays are counted once
-    job_rays = stats["rays_camera"] + (stats["rays_probe"] if (not tile or rank == 0) else 0)
+    job_rays = (stats["rays_camera"] + (stats["rays_probe"] if (not tile or rank == 0) else 0)) / n_blocks
     t_rays = torch.tensor([float(job_rays), dt], dtype=torch.float64, device="cuda")
     if dist is not None:
         tmax = t_rays.clone()
@@ -301,29 +333,38 @@ def main():
         launches = max(stats["traverse_launches"], 1)
         timed = max(stats["traverse_launches_timed"], 1)
         mean_launch_ms = stats["traverse_ms"] / timed
-        rays_per_launch = rays / launches
-        rays_timed = rays * timed / launches  # frames are statistically alike: the timed launches carry their share of the rays
+        rays_all = rays * n_blocks                       # the stats cover all timed blocks
+        rays_per_launch = rays_all / launches
+        rays_timed = rays_all * timed / launches  # frames are statistically alike: the timed launches carry their share of the rays
         model_gbs = (b_trav * rays_per_launch) / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
         # queued (scattered / sample-point: incoherent) launches apart from the bounce-0 launches: north_star's
         # ">= 1 Grays/s incoherent secondary rays" is read off `secondary_Mrays_s`
         sec_launches = stats["traverse_launches"] - stats["primary_launches"]
         sec_timed = stats["traverse_launches_timed"] - stats["primary_launches_timed"]
         sec_ms = stats["traverse_ms"] - stats["primary_ms"]
-        sec_rays = rays - stats["rays_primary"]
+        sec_rays = rays_all - stats["rays_primary"]
         secondary = primary = None
         if sec_timed > 0 and sec_ms > 0 and sec_launches > 0:
             secondary = (sec_rays * sec_timed / sec_launches) / (sec_ms * 1e-3) / 1e6
         if stats["primary_launches_timed"] > 0 and stats["primary_ms"] > 0:
             primary = (stats["rays_primary"] * stats["primary_launches_timed"] / stats["primary_launches"]) / (stats["primary_ms"] * 1e-3) / 1e6
-        # per-launch counters of k_traverse from the committed PMC passes of this same command (tools/pmc_passes.sh +
-        # tools/pmc_summary.py -> profiles/pmc_traffic.json; HBM bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB per the gfx950
-        # note of MI355X_MICROARCH.md); only for the workload they were taken on
-        pmc = None
-        if (args.width, args.height) == (1920, 1080) and world == 1:
+        # per-launch counters from the committed PMC passes of this same command (tools/pmc_passes.sh + tools/pmc_summary.py
+        # -> profiles/pmc_traffic.json, one entry per workload and size; HBM bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB per the
+        # gfx950 note of MI355X_MICROARCH.md).  An entry is used only while the kernel sources are the ones it was taken on
+        # (`source_hash`): otherwise the counter-based figures are null and `pmc_note` says why -- never a fraction that mixes
+        # another build's instruction count with this build's timing.
+        pmc_all, pmc, pmc_note = None, None, None
+        key = pmc_key(args)
+        if world == 1:
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[args.workload]["kernels"]["k_traverse"]
+                entry = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[key]
+                if entry.get("source_hash") != pmc_summary.source_hash(ROOT):
+                    pmc_note = "profiles/pmc_traffic.json[%r] was taken on other kernel sources (%s): rerun tools/pmc_passes.sh" % (key, entry.get("source_hash"))
+                else:
+                    pmc_all = entry["kernels"]
+                    pmc = pmc_all.get("k_traverse")
             except (OSError, KeyError, ValueError):
-                pmc = None
+                pmc_note = "no PMC passes committed for %r" % key
         cyc_best, cyc_mix = valu_issue_cycles()
         traffic = insts = achieved = peak = frac = traffic_frac = mix_frac = valu_busy = None
         if pmc is not None:
@@ -336,25 +377,43 @@ def main():
             peak = SIMDS * CLOCK_GHZ / cyc_best
             frac = achieved / peak
             mix_frac = achieved * cyc_mix / (SIMDS * CLOCK_GHZ) if cyc_mix else None
-            assert frac <= 1.0, "roofline.frac %g > 1: the PMC pass in profiles/ does not belong to this build" % frac
-            if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
+            if frac > 1.0:  # cannot be: more instructions per second than the SIMDs can issue
+                pmc_note = "roofline.frac %.3f > 1: the PMC pass in profiles/ does not fit this run; counter-based figures dropped" % frac
+                achieved = frac = mix_frac = None
+            elif pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
                 # the hardware's own tally, from the PMC run itself: quad-cycles in which a SIMD executes a vector
                 # instruction over the SIMD quad-cycles of the launch (GRBM_GUI_ACTIVE sums the 8 XCDs)
                 valu_busy = 4.0 * pmc["SQ_ACTIVE_INST_VALU"] / (SIMDS * pmc["GRBM_GUI_ACTIVE"] / 8.0)
+        # the other kernels of a step, from the same passes: vector instructions and HBM bytes per launch, the launch time
+        # under the profiler (one kernel at a time on the GPU) and what that makes of the two ceilings
+        other = None
+        if pmc_all is not None:
+            other = {}
+            for name, k in sorted(pmc_all.items()):
+                if name.startswith("k_traverse") or "<" in name and name.split("<")[0] in pmc_all and not name.startswith(("k_shade", "k_gather")):
+                    continue
+                ns = k.get("duration_ns")
+                e = {"launches_sampled": k.get("launches_sampled"), "valu_insts_per_launch": k.get("SQ_INSTS_VALU"),
+                     "traffic_bytes_per_launch": k.get("traffic_bytes_per_launch"), "launch_us_under_pmc": ns / 1e3 if ns else None}
+                if ns and k.get("traffic_bytes_per_launch") is not None:
+                    e["hbm_frac"] = k["traffic_bytes_per_launch"] / ns / HBM_PEAK_GBS
+                if ns and k.get("SQ_INSTS_VALU") is not None and cyc_best:
+                    e["valu_issue_frac"] = k["SQ_INSTS_VALU"] / ns / (SIMDS * CLOCK_GHZ / cyc_best)
+                other[name] = e
         # the whole frame: vector instructions of ALL its kernels (the same PMC passes; c2 runs each of the five once per frame)
         # against the issue slots of the frame's wall time, at the measured cost of the node step's blend.  With two frames
         # in flight the kernels overlap, so this -- not the per-launch figure -- says how full the machine is.
         frame_insts = frame_issue_frac = None
-        if pmc is not None and args.workload == "c2" and cyc_mix:
+        if pmc_all is not None and args.workload == "c2" and cyc_mix:
             try:
-                ks = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["c2"]["kernels"]
+                ks = pmc_all
                 def timed_traverse(primary):  # the instantiation the timed frames ran (not the counting one): the most launches
                     cand = [k for k in ks if k.startswith("k_traverse<false, ") and k.split(", ")[2] == primary]
                     return max(cand, key=lambda k: ks[k]["launches_sampled"])
                 per_frame = [timed_traverse("true"), timed_traverse("false"), "k_shade<true, true>", "k_shade<false, true>", "k_frame_resolve"]
                 frame_insts = sum(ks[k]["SQ_INSTS_VALU"] for k in per_frame)
                 frame_issue_frac = frame_insts * cyc_mix / (dt_max / args.steps * SIMDS * CLOCK_GHZ * 1e9)
-            except (OSError, KeyError, ValueError):
+            except (KeyError, ValueError):
                 frame_insts = frame_issue_frac = None
         split_label = ("tile split x%d" if tile else "sample-set split x%d") % world
         out = {
@@ -364,6 +423,7 @@ def main():
             "value": total_rays / dt_max / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll_steps,
+            "timed_blocks": n_blocks, "block_ms": [round(b * 1e3, 4) for b in block_s],   # value: the median block (+ the exchange)
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if tile else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -374,9 +434,11 @@ def main():
                        "frames_in_flight": out_frames_in_flight(args)},
             "primary_Mrays_s": primary,        # bounce-0 launches alone (coherent), from their launch durations
             "secondary_Mrays_s": secondary,    # queued launches alone (scattered / sample-point rays: incoherent)
-            "reduce_ms": reduce_ms if world > 1 else None,   # the one collective, inside the timed region (rank 0's view)
+            "reduce_ms": reduce_ms if world > 1 else None,   # the one exchange step, part of the timed job (rank 0's view)
+            "exchange": None if world == 1 else {"kind": "gather of owned tiles" if tile else "reduce(sum) of the accumulator",
+                                                 "bytes_per_rank": exchange_bytes},
             "roofline": {"bound": "valu_issue", "kernel": "k_traverse", "achieved": achieved, "peak": peak, "unit": "Ginst/s",
-                         "frac": frac, "traffic": traffic, "traffic_frac": traffic_frac,
+                         "frac": frac, "traffic": traffic, "traffic_frac": traffic_frac, "pmc_entry": key, "pmc_note": pmc_note,
                          "valu_insts_per_launch": insts, "cycles_per_inst_best": cyc_best, "cycles_per_inst_node_step_mix": cyc_mix,
                          # the same instruction rate priced at the measured cost of the node step's instruction blend
                          # (selects, v_fma_mix, min / max run at half the fma rate on gfx950): how full the issue slots are
@@ -399,6 +461,7 @@ def main():
                              alone, achieved=None if insts is None else insts / (alone["mean_launch_ms"] * 1e-3) / 1e9,
                              frac=None if (insts is None or peak is None) else insts / (alone["mean_launch_ms"] * 1e-3) / 1e9 / peak)},
             "cpu_baseline": cpu_line,
+            "other_kernels": other,
         }
         # acceleration-structure builds are outside the timed loop: reported separately
         out["build"] = {"last_blas_ms": stats["blas_build_ms"], "blas_triangles_total": stats["blas_triangles"],
@@ -421,7 +484,15 @@ def main():
             pairs_s = stats["gather_pairs"] * gtimed / stats["gather_launches"] / (stats["gather_ms"] * 1e-3)
             out["gather"] = {"kernel": "k_gather", "pairs_per_s": pairs_s, "lds_GB_per_s": 24.0 * pairs_s / 1e9,
                              "mean_launch_ms": stats["gather_ms"] / gtimed,
-                             "share_of_step": stats["gather_ms"] / gtimed * stats["gather_launches"] / (dt * 1e3)}
+                             "share_of_step": stats["gather_ms"] / gtimed * stats["gather_launches"] / (sum(block_s) * 1e3)}
+            gp = (pmc_all or {}).get("k_gather")
+            if gp and gp.get("SQ_INSTS_VALU") and cyc_best:
+                # second roofline: the gather is bound by vector-instruction issue too (sqrt / filter arithmetic per pair)
+                g_ach = gp["SQ_INSTS_VALU"] / (out["gather"]["mean_launch_ms"] * 1e-3) / 1e9
+                out["gather"]["roofline"] = {"bound": "valu_issue", "achieved": g_ach, "peak": SIMDS * CLOCK_GHZ / cyc_best, "unit": "Ginst/s",
+                                             "frac": g_ach / (SIMDS * CLOCK_GHZ / cyc_best), "valu_insts_per_launch": gp["SQ_INSTS_VALU"],
+                                             "traffic": gp.get("traffic_bytes_per_launch"),
+                                             "lds_bank_conflict_share": (gp["SQ_LDS_BANK_CONFLICT"] / gp["SQ_LDS_ACTIVE"]) if gp.get("SQ_LDS_ACTIVE") else None}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

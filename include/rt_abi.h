@@ -27,7 +27,10 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+/* 2: RtStats as it stands below (it grew after version 1 shipped), rt_dispatch_rays_static, rt_resolve_render_target_frames,
+ *    rt_tile_pack_bytes / rt_pack_tiles / rt_unpack_tiles.  A caller compares rt_abi_version() with the RT_ABI_VERSION it was
+ *    built against before it passes any struct (raytracer_amd/api.py and host/raytracing.hpp do). */
+#define RT_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------------------- */
 enum {
@@ -250,6 +253,20 @@ int  rt_set_tile_split(rt_ctx* ctx, uint32_t rank, uint32_t world);
 int  rt_accumulator_device_ptr(rt_ctx* ctx, void** dev_ptr, size_t* bytes);
 /* Re-run the resolve step (raytracing.hlsl:161) after the caller has summed accumulators across ranks. */
 int  rt_resolve_render_target(rt_ctx* ctx);
+/* The same with an explicit frame count: after a sample-set split every rank's accumulator_count is its own share of the
+ * frames, while the summed accumulator holds total_frames of them.  The context's globals are left as they are. */
+int  rt_resolve_render_target_frames(rt_ctx* ctx, uint32_t total_frames);
+/* Tile split: collecting the image by exchanging only the tiles each rank owns (1 / world of the frame per rank) instead
+ * of summing whole frames.  rt_tile_pack_bytes: size of one rank's packed tiles -- ceil(tiles / world) x 1,024 pixels x
+ * 16 B, the same on every rank, so that an all_gather / gather of equal blocks works.  rt_pack_tiles: copies the
+ * accumulator pixels of the tiles of `rank` (tile t with t % world == rank, in increasing t; inside a tile in the order
+ * of the renderer's threads; slots outside the image and a missing last tile are zero) into the caller's device buffer.
+ * rt_unpack_tiles: the reverse, into this context's accumulator (the 8-bit target is re-derived at the next read).
+ * Stream-ordered on the context's stream like everything else; the caller synchronises (rt_sync) before handing the
+ * buffer to a collective on another stream.  Plain copies: bit-identical to the sum of the ranks' frames. */
+int  rt_tile_pack_bytes(rt_ctx* ctx, uint32_t world, size_t* bytes);
+int  rt_pack_tiles(rt_ctx* ctx, uint32_t rank, uint32_t world, void* dev_packed);
+int  rt_unpack_tiles(rt_ctx* ctx, uint32_t rank, uint32_t world, const void* dev_packed);
 
 #ifdef __cplusplus
 }

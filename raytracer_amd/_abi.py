@@ -11,6 +11,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 DATA_DIR = os.path.join(PKG_DIR, "data")
 
+RT_ABI_VERSION = 2   # include/rt_abi.h
 RT_OK = 0
 RT_SHADER_LAMBERT, RT_SHADER_LIGHT, RT_SHADER_TRANSLUCENT = 0, 1, 2
 RT_FLAG_COLLECT_SAMPLES = 1 << 0

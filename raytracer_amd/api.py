@@ -10,6 +10,9 @@ _LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(_abi.PKG_DIR, "librt_m
 _lib = _abi.load_library(_LIB_PATH)
 _lib.rt_last_error.restype = C.c_char_p
 _lib.rt_abi_version.restype = C.c_int
+if _lib.rt_abi_version() != _abi.RT_ABI_VERSION:  # struct layouts below (RtStats) belong to one version of include/rt_abi.h
+    raise ImportError("%s has ABI version %d, this binding is for version %d: rebuild with `make`"
+                      % (_LIB_PATH, _lib.rt_abi_version(), _abi.RT_ABI_VERSION))
 
 
 def last_error():
@@ -65,3 +68,18 @@ class Raytracer(_abi.Backend):
 
     def resolve_render_target(self):
         self._call("resolve_render_target")
+
+    def resolve_render_target_frames(self, total_frames):
+        self._call("resolve_render_target_frames", C.c_uint32(total_frames))
+
+    # tile split: exchange of the owned tiles only (include/rt_abi.h)
+    def tile_pack_bytes(self, world):
+        n = C.c_size_t()
+        self._call("tile_pack_bytes", C.c_uint32(world), C.byref(n))
+        return n.value
+
+    def pack_tiles(self, rank, world, dev_ptr):
+        self._call("pack_tiles", C.c_uint32(rank), C.c_uint32(world), C.c_void_p(dev_ptr))
+
+    def unpack_tiles(self, rank, world, dev_ptr):
+        self._call("unpack_tiles", C.c_uint32(rank), C.c_uint32(world), C.c_void_p(dev_ptr))

@@ -907,7 +907,9 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
     RT_HIP(hipMalloc(&c->d_tlas_perm, 4 * (size_t) n_prims));
     RT_HIP(hipMemcpyAsync(c->d_inst_rec, rec.data(), sizeof(InstRec) * n, hipMemcpyHostToDevice, c->stream));
     RT_HIP(hipMemcpyAsync(c->d_inst_shade, shade.data(), sizeof(InstShade) * n, hipMemcpyHostToDevice, c->stream));
-    int rc = lbvh_workspace_reserve(c->lbvh, n_prims); if (rc) return rc;
+    // lbvh_instance_boxes writes the boxes of all n instances (the inlined one's too: lbvh_move_box reads boxes[n - 1]);
+    // the build below then covers the first n_prims of them
+    int rc = lbvh_workspace_reserve(c->lbvh, (u32) n); if (rc) return rc;
     RT_HIP(hipEventRecord(c->build_ev[0], c->stream));
     const bool exact_boxes = c->exact_instance_boxes && vertex_work <= (4ull << 30);
     rc = lbvh_instance_boxes(c->stream, c->lbvh, c->d_inst_shade, c->d_inst_rec, (u32) n, exact_boxes); if (rc) return rc;
@@ -1397,6 +1399,52 @@ int rt_resolve_render_target(rt_ctx* c) {
     PassArgs a; fill_pass_args(c, a, false);
     c->render_target_stale = false;
     return launch_resolve_only(c->stream, a);
+}
+
+int rt_resolve_render_target_frames(rt_ctx* c, uint32_t total_frames) {
+    if (!c || !c->d_accumulator || total_frames == 0) { set_error("rt_resolve_render_target_frames: bad arguments"); return RT_ERR_INVALID; }
+    { int qrc = quiesce(c); if (qrc) return qrc; }
+    PassArgs a; fill_pass_args(c, a, false);
+    a.g.accumulator_count = total_frames; // the context's own count (this rank's share of the frames) stays as it is
+    c->render_target_stale = false;
+    return launch_resolve_only(c->stream, a);
+}
+
+namespace {
+// PassArgs naming the tiles of rank `rank` of `world` (thread_pixel, rt_kernels.hip)
+void tile_args(rt_ctx* c, PassArgs& a, u32 rank, u32 world) {
+    fill_pass_args(c, a, false);
+    const u32 n_tiles = a.tiles_x * a.tiles_y;
+    a.tile_rank = rank; a.tile_world = world;
+    a.n_local_tiles = n_tiles > rank ? (n_tiles - rank + world - 1) / world : 0;
+}
+} // namespace
+
+int rt_tile_pack_bytes(rt_ctx* c, uint32_t world, size_t* bytes) {
+    if (!c || !bytes || world == 0 || c->width == 0) { set_error("rt_tile_pack_bytes: bad arguments"); return RT_ERR_INVALID; }
+    const size_t n_tiles = (size_t) ((c->width + 31) / 32) * ((c->height + 31) / 32);
+    *bytes = ((n_tiles + world - 1) / world) * 1024 * 16; // the most tiles any rank owns: the same size on every rank
+    return RT_OK;
+}
+
+int rt_pack_tiles(rt_ctx* c, uint32_t rank, uint32_t world, void* dev_packed) {
+    if (!c || !dev_packed || world == 0 || rank >= world || !c->d_accumulator) { set_error("rt_pack_tiles: bad arguments"); return RT_ERR_INVALID; }
+    RT_HIP(hipSetDevice(c->device));
+    { int qrc = quiesce(c); if (qrc) return qrc; }
+    PassArgs a; tile_args(c, a, rank, world);
+    size_t bytes = 0; (void) rt_tile_pack_bytes(c, world, &bytes);
+    if ((size_t) a.n_local_tiles * 1024 * 16 < bytes) // a rank with one tile less than the largest share: the tail is defined too
+        RT_HIP(hipMemsetAsync((char*) dev_packed + (size_t) a.n_local_tiles * 1024 * 16, 0, bytes - (size_t) a.n_local_tiles * 1024 * 16, c->stream));
+    return launch_pack_tiles(c->stream, a, dev_packed);
+}
+
+int rt_unpack_tiles(rt_ctx* c, uint32_t rank, uint32_t world, const void* dev_packed) {
+    if (!c || !dev_packed || world == 0 || rank >= world || !c->d_accumulator) { set_error("rt_unpack_tiles: bad arguments"); return RT_ERR_INVALID; }
+    RT_HIP(hipSetDevice(c->device));
+    { int qrc = quiesce(c); if (qrc) return qrc; }
+    PassArgs a; tile_args(c, a, rank, world);
+    c->render_target_stale = true; c->render_target_frames = c->g.accumulator_count;
+    return launch_unpack_tiles(c->stream, a, dev_packed);
 }
 
 } // extern "C"

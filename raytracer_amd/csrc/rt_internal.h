@@ -200,6 +200,9 @@ int launch_camera_resolve(hipStream_t s, const PassArgs& a);
 int launch_frame_resolve(hipStream_t s, const PassArgs& a); // pipelined frames: adds the sample sums the fused shades left in ps.sum_* (a.defer_resolve)
 int launch_probe_resolve(hipStream_t s, const PassArgs& a);
 int launch_fill_capture(hipStream_t s, const PassArgs& a);
+// tile split: the accumulator pixels of the tiles of rank a.tile_rank of a.tile_world, packed (1,024 float4 per tile) / written back
+int launch_pack_tiles(hipStream_t s, const PassArgs& a, void* packed);
+int launch_unpack_tiles(hipStream_t s, const PassArgs& a, const void* packed);
 int launch_resolve_only(hipStream_t s, const PassArgs& a); // raytracing.hlsl:161 after an external accumulator sum
 
 // ---- blue-noise sample points (rt_bluenoise.hip) ----------------------------------------------------------------

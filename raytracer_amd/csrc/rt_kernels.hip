@@ -271,6 +271,22 @@ __global__ __launch_bounds__(BT) void k_resolve_only(PassArgs a) {
                                                       to_unorm8(sqrtf(v.z / denom)), to_unorm8(sqrtf(v.w / denom)));
 }
 
+// Tile split over ranks (rt_set_tile_split): the accumulator pixels of the tiles one rank owns, packed tile after tile
+// (1,024 float4 per tile in thread_pixel order; slots outside the image are zero) -- what a rank sends instead of its
+// whole, mostly untouched, frame -- and the way back into the accumulator of the rank that collects them.  `a` carries
+// the rank / world whose tiles are meant.  Plain copies: the collected image equals the sum of the ranks' frames bit for bit.
+__global__ __launch_bounds__(BT) void k_pack_tiles(PassArgs a, float4* __restrict__ packed) {
+    const u32 t = blockIdx.x * BT + threadIdx.x;
+    if (t >= a.n_local_tiles * 1024u) return;
+    u32 px, py;
+    packed[t] = thread_pixel(a, t, px, py) ? ((const float4*) a.accumulator)[py * a.width + px] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+__global__ __launch_bounds__(BT) void k_unpack_tiles(PassArgs a, const float4* __restrict__ packed) {
+    const u32 t = blockIdx.x * BT + threadIdx.x;
+    u32 px, py;
+    if (thread_pixel(a, t, px, py)) ((float4*) a.accumulator)[py * a.width + px] = packed[t];
+}
+
 RT_DEV void probe_finish_sample(const PassArgs& a, u32 p, f3 normal, f3& tsum) { // raytracing.hlsl:257-261
     f3 radiance = mk3(a.ps.rad_x[p], a.ps.rad_y[p], a.ps.rad_z[p]);
     f3 fd = mk3(a.ps.fd_x[p], a.ps.fd_y[p], a.ps.fd_z[p]);
@@ -1235,6 +1251,20 @@ int launch_fill_capture(hipStream_t s, const PassArgs& a) {
     if (!a.capture) return RT_OK;
     size_t n = (size_t) (a.g.bounces_per_sample + 1) * a.width * a.height;
     hipLaunchKernelGGL(k_fill_capture, blocks(n, BT), dim3(BT), 0, s, a.capture, n);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+int launch_pack_tiles(hipStream_t s, const PassArgs& a, void* packed) {
+    size_t threads = (size_t) a.n_local_tiles * 1024;
+    if (!threads) return RT_OK;
+    hipLaunchKernelGGL(k_pack_tiles, blocks(threads, BT), dim3(BT), 0, s, a, (float4*) packed);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+int launch_unpack_tiles(hipStream_t s, const PassArgs& a, const void* packed) {
+    size_t threads = (size_t) a.n_local_tiles * 1024;
+    if (!threads) return RT_OK;
+    hipLaunchKernelGGL(k_unpack_tiles, blocks(threads, BT), dim3(BT), 0, s, a, (const float4*) packed);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

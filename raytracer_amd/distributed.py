@@ -69,10 +69,16 @@ def require_no_sample_points(backend):
 def resolve_reduced(backend, total_frames):
     """raytracing.hlsl:161 on an accumulator that now holds `total_frames` frames (after the reduce over ranks): the
     rank's own accumulator_count is one rank's share, so the count is set before the resolve."""
+    if hasattr(backend, "resolve_render_target_frames"):   # the product: explicit count, the context's globals stay untouched
+        backend.resolve_render_target_frames(int(total_frames))
+        return
     g = backend.get_globals()
+    own = g.accumulator_count
     g.accumulator_count = int(total_frames)
     backend.set_globals(g)
     backend.resolve_render_target()
+    g.accumulator_count = own          # later dispatches of this rank go on from its own count (raytracing.hlsl:155-161)
+    backend.set_globals(g)
 
 
 def device_accumulator(rt, device):
@@ -85,6 +91,33 @@ def device_accumulator(rt, device):
     b = _Buf()
     b.__cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 3, "strides": None}
     return torch.as_tensor(b, device=device)
+
+
+def gather_tiles(rt, dist, rank, world, device, dst=0, via_host=False):
+    """Tile split: the one exchange step as a gather of the tiles each rank OWNS (1 / world of the frame per rank) instead
+    of a reduce(sum) of whole, mostly untouched frames.  Over xGMI every rank sends its share straight to
+    `dst` on its own link: 7/8 of one frame arrives at dst in all, against the 2 (N-1)/N frames a ring reduce moves
+    through every link.  Pixels are copied, not added: bit-identical to the sum of zero-filled frames.
+    via_host: stage through host memory (gloo rehearsal on one GPU: gloo has no device gather)."""
+    import torch
+    nbytes = rt.tile_pack_bytes(world)
+    mine = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    rt.pack_tiles(rank, world, mine.data_ptr())
+    rt.sync()                                   # the pack ran on the library's stream; the collective runs on torch's
+    if via_host:
+        parts = [torch.empty(nbytes // 4, dtype=torch.float32) for _ in range(world)] if rank == dst else None
+        dist.gather(mine.cpu(), parts, dst=dst)
+        parts = [p.to(device) for p in parts] if rank == dst else None
+    else:
+        parts = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+        dist.gather(mine, parts, dst=dst)
+        torch.cuda.synchronize()
+    if rank == dst:
+        for r in range(world):
+            if r != rank:
+                rt.unpack_tiles(r, world, parts[r].data_ptr())
+        rt.sync()                               # `parts` must outlive the copies
+    return nbytes
 
 
 def reduce_accumulator(tensor, dist, dst=0, all_ranks=False):

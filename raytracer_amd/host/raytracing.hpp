@@ -43,6 +43,7 @@ inline void check(int rc, const char* what) {
 
 // Raytracing::init (raytracing.cpp:73): creates the context and uploads the BSSRDF tables (3 x n floats: r, g, b)
 inline void init(int device, const float* skin0_rgb, const float* skin1_rgb, uint32_t n) {
+    if (rt_abi_version() != RT_ABI_VERSION) { fprintf(stderr, "librt_mi355x.so has ABI version %d, this caller was built against %d\n", rt_abi_version(), RT_ABI_VERSION); abort(); }
     check(rt_create(&device, 1, &ctx()), "rt_create");
     if (skin0_rgb) check(rt_load_bssrdf_table(ctx(), 0, skin0_rgb, skin0_rgb + n, skin0_rgb + 2 * n, n), "rt_load_bssrdf_table");
     if (skin1_rgb) check(rt_load_bssrdf_table(ctx(), 1, skin1_rgb, skin1_rgb + n, skin1_rgb + 2 * n, n), "rt_load_bssrdf_table");

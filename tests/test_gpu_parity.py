@@ -92,6 +92,14 @@ def test_c5_instanced_field_small(oracle_mod):
     _check_scene(scene, oracle_mod, frames=2, brute_force=False)
 
 
+def test_instance_count_that_fills_the_build_workspace_exactly(oracle_mod):
+    """2,048 bunnies + the inlined floor: rt_build_tlas writes 2,049 instance boxes while the top level holds 2,048
+    primitives, and 2,048 boxes of 24 bytes end exactly on a page boundary -- the workspace must hold all n boxes
+    (it was sized for n - 1: the last box landed past the allocation)"""
+    scene = scenes.bunny_field(160, 90, spp=1, bounces=2, grid=48, count=2048)
+    _check_scene(scene, oracle_mod, frames=1, brute_force=False)
+
+
 def test_many_instances_of_tiny_blas(oracle_mod):
     """TLAS-heavy case: 1500 instances of the 12-triangle cube, brute-force oracle"""
     from raytracer_amd import host
