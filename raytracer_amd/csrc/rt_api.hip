@@ -97,6 +97,7 @@ struct rt_ctx {
     u32 n_paths = 0; float* d_arena = nullptr;
     RayQueue q[2]; HitBuf hits; PathState ps; SlotState st[2]; GatherQueue gq; int* d_stack_spill = nullptr;
     u32* d_task_counter = nullptr; u32 persistent_slots = 0; int persistent = 0; // RT_PERSISTENT: 0 never (default), bit 0 queued launches, bit 1 primary launches
+    int pool = 0; u32 cu_count = 0; // RT_POOL=2: pooled traversal for the queued launches of two-level scenes (rt_dev_pool.h), workgroups per CU; off by default (profiles/r03_ab_pool_c5.txt: right, and 2-4x slower)
     int wave_major = 1; // RT_WAVE_MAJOR
     int xcd_bands = 1;  // RT_XCD_BANDS
     int ray_sort = 1; // RT_RAY_SORT: group the surviving rays of a bounce by direction octant (fused camera pass)
@@ -279,6 +280,14 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     // persistent traversal waves pay ~2.5 us per 64-ray task and win back the dispatcher's idle slots; since the dispatched
     // kernels run 6 waves per SIMD in wave-major order that no longer pays on any benchmark scene (k_traverse, rt_kernels.hip)
     a.persistent = c->persistent > 0 ? (u32) c->persistent : 0u;
+    a.pool_groups = c->pool > 0 ? (u32) c->pool * c->cu_count : 0u;
+    a.dbg_blas_lo = ~0ull; a.dbg_blas_hi = 0ull;
+    for (const Blas& b : c->blas) {
+        const u32 nn = b.n_tris > 1 ? b.n_tris - 1 : 1;
+        const unsigned long long lo = (unsigned long long) b.d_nodes, hi = lo + nn * sizeof(PackedNode) + 3ull * b.n_tris * sizeof(TriRec);
+        a.dbg_blas_lo = std::min(a.dbg_blas_lo, lo); a.dbg_blas_hi = std::max(a.dbg_blas_hi, hi);
+    }
+    { const u32 np = c->n_instances - (c->inl_inst >= 0 ? 1u : 0u); a.dbg_tlas_bytes = (np > 1 ? np - 1 : 1) * (u32) sizeof(PackedNode); }
     a.st[0] = c->st[0]; a.st[1] = c->st[1];
     for (int k = 0; k < 3; k++) a.camera_origin[k] = c->g.camera_to_world[12 + k] / c->g.camera_to_world[15];
     a.fudge = (c->flags & RT_FLAG_ENABLE_SSS) ? c->g.translucent_bssrdf_fudge : 0.0f;
@@ -654,6 +663,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_SAH_TRI")) c->sah_tri = (float) atof(v);
     if (const char* v = getenv("RT_RAY_SORT")) c->ray_sort = atoi(v);
     if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
+    if (const char* v = getenv("RT_POOL")) c->pool = atoi(v);
     if (const char* v = getenv("RT_XCD_BANDS")) c->xcd_bands = atoi(v);
     if (const char* v = getenv("RT_SORT_BOX")) c->sort_box = atoi(v);
     if (const char* v = getenv("RT_SORT_CHORD")) c->sort_chord_pct = (float) atof(v);
@@ -670,6 +680,8 @@ int create_context(rt_ctx* c) {
     hipDeviceProp_t prop;
     RT_HIP(hipGetDeviceProperties(&prop, c->device));
     c->persistent_slots = (u32) prop.multiProcessorCount * 4u * 5u;
+    c->cu_count = (u32) prop.multiProcessorCount;
+    if (c->pool == 1 || c->pool > 2) c->pool = 2; // two 256-ray pools per CU: what their LDS allows
     RT_HIP(hipMalloc(&c->d_task_counter, 65 * 128));
     RT_HIP(hipMemset(c->d_task_counter, 0, 65 * 128));
     RT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -1357,6 +1369,15 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
     int rc = drain_timers(c); if (rc) return rc;
     DeviceStats ds;
     RT_HIP(hipMemcpy(&ds, c->d_stats, sizeof ds, hipMemcpyDeviceToHost));
+#if defined(RT_POOL_DEBUG)
+    if (ds.pool_err[0]) {
+        fprintf(stderr, "RT_POOL_DEBUG: pooled traversal caught violation code %llu value 0x%llx", ds.pool_err[0], ds.pool_err[1]);
+        for (int k = 2; k < 8; k++) fprintf(stderr, " 0x%llx", ds.pool_err[k]);
+        PassArgs a; fill_pass_args(c, a, false);
+        fprintf(stderr, " | blas range 0x%llx..0x%llx tlas bytes %u\n", a.dbg_blas_lo, a.dbg_blas_hi, a.dbg_tlas_bytes);
+    }
+    else fprintf(stderr, "RT_POOL_DEBUG: no violation\n");
+#endif
     memset(out, 0, sizeof *out);
     out->rays_camera = ds.rays_camera + c->primary_rays; out->rays_probe = ds.rays_probe; out->gather_pairs = ds.gather_pairs;
     out->nodes_visited = ds.nodes; out->tris_tested = ds.tris; out->instances_entered = ds.insts;

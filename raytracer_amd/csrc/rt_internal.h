@@ -133,6 +133,7 @@ struct HgView {
 
 struct DeviceStats { // lives in device memory
     unsigned long long rays_camera, rays_probe, gather_pairs, nodes, tris, insts, node_trips, tri_trips, inst_trips, max_ray_steps;
+    unsigned long long pool_err[8]; // RT_POOL_DEBUG builds: first bounds violation the pooled traversal caught (code, value)
     unsigned long long hg_overflow; // k_gather_hg ran out of walk stack and dropped a subtree: the host reports RT_ERR_LIMIT (rt_sync, rt_get_stats, reads)
 };
 
@@ -142,6 +143,8 @@ struct PassArgs {
     u32* task_counter;           // persistent traversal: 64 task counters + 1 done counter, 128 bytes apart; all zero between launches
     u32 persistent_slots;        // wave slots of the device for the traversal kernel (CUs x 4 SIMDs x 5 waves), 0 = never persistent
     u32 persistent;              // bit 0: queued (secondary / probe) launches persistent, bit 1: primary launches too
+    u32 pool_groups;             // > 0: queued launches of two-level scenes run the pooled traversal (rt_dev_pool.h) on this many persistent workgroups (RT_POOL)
+    unsigned long long dbg_blas_lo, dbg_blas_hi; u32 dbg_tlas_bytes; // RT_POOL_DEBUG builds: address range of all bottom-level trees, size of the top-level node array
     u32 lazy_render_target;      // the resolve leaves the render target alone (rt_api.hip derives it from the accumulator when it is read)
     u32 defer_resolve;           // fused camera pass: finished paths leave their pixel's sample sum in ps.sum_* for k_frame_resolve
     u32 stack_in_lds;            // the trees are shallow enough for the LDS rows of the traversal stack alone (LaneStack<false>)

@@ -14,6 +14,7 @@
 // MI355X, which made a 2 M-ray launch cost 0.37 ms), slot assignment is deterministic, and the 16 waves that the
 // traverse kernel runs per segment are dense except for the last one.
 #include "rt_internal.h"
+#include "rt_dev_pool.h"
 
 namespace rti {
 
@@ -491,6 +492,330 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
         const u32 done = atomicAdd(a.task_counter + TASK_PARTS * TASK_STRIDE, 1u);
         if (done == gridDim.x - 1u) for (u32 k = 0; k <= TASK_PARTS; k++) a.task_counter[k * TASK_STRIDE] = 0u;
     }
+}
+
+// ---- pooled traversal of two-level scenes (rt_dev_pool.h) ---------------------------------------------------------------
+// Queued launches only (bounce-0 rays are coherent and keep k_traverse).  One workgroup = 4 waves = a pool of 256 rays
+// in LDS; grid = the workgroups that fit the GPU at once (2 per CU by their ~70 KB of LDS), each working through the
+// queue segments g, g + G, g + 2 G, ... (G = grid size).  ROWS = stack rows per ray (17 / 33, as for k_traverse).
+static constexpr int POOL_NODE_STEPS_MAX = 12; // a NODE batch goes back to the pool after this many steps at the latest
+// RT_POOL_DEBUG (a separate build, tools/build_pool_debug.sh): every index and address the pooled kernel is about to use is
+// checked against the scene's bounds first; a violation is recorded in DeviceStats::pool_err (code, value: the first one
+// wins) and the ray is ended instead of the access being made -- a wild access takes the GPU down with it.
+#if defined(RT_POOL_DEBUG)
+#define RT_POOL_CHECK(cond, code, value, on_fail) if (!(cond)) { if (atomicCAS(&a.stats->pool_err[0], 0ull, (unsigned long long) (code)) == 0ull) a.stats->pool_err[1] = (unsigned long long) (value); on_fail; }
+#else
+#define RT_POOL_CHECK(cond, code, value, on_fail)
+#endif
+// Workgroup barrier of the pooled kernel: the LDS stores of this wave have landed before any other wave goes on.  The wait is
+// explicit: at the barrier that heads the round loop hipcc (ROCm 7.2) emitted a bare s_barrier -- the wait that __syncthreads()'s
+// release fence asks for was dropped on the loop's back edge -- and, once in ~10^8 rays, a wave read the class of a ray
+// before the store of the round before had landed: the ray then sat in two lists and was walked by two waves at once.
+RT_DEV void pool_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    __syncthreads();
+}
+template <bool COUNT, int ROWS>
+__global__ __launch_bounds__(POOL_RAYS, 2) void k_traverse_pool(PassArgs a, u32 inq) {
+    extern __shared__ int pool_lds[];
+    RT_LDS int* const s_stack = (RT_LDS int*) pool_lds;                 // [ROWS][POOL_RAYS]
+    RT_LDS int* const s_f = s_stack + ROWS * POOL_RAYS;                 // [PF_COUNT][POOL_RAYS]
+    RT_LDS int* const s_list = s_f + PF_COUNT * POOL_RAYS;              // [4][POOL_RAYS]: slots by class
+    RT_LDS int* const s_wc = s_list + 4 * POOL_RAYS;                    // [5][4]: rays per class and wave, pending results per wave
+    RT_LDS int* const s_src = s_wc + 20;                                // the queue segment being fed into the pool: index, next ray, fill
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const SceneView& sc = a.scene;
+    TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
+    auto fi = [&](int f, u32 slot) -> RT_LDS int& { return s_f[f * POOL_RAYS + slot]; };
+    auto ff = [&](int f, u32 slot) -> RT_LDS float& { return ((RT_LDS float*) s_f)[f * POOL_RAYS + slot]; };
+    const u32 seg_stride = gridDim.x;
+    // the top level's box-test constants of a ray wait in global memory while it is inside an instance: three float4 per queue
+    // slot in the (otherwise unused) overflow rows of the traversal stack
+    float4* const side = (float4*) a.stack_spill;
+    s_stack[tid] = RT_TRAVERSAL_DONE; // row 0: the sentinel under every stack
+    fi(PF_CLS, tid) = PC_FREE; fi(PF_QI, tid) = -1; fi(PF_CUR, tid) = RT_TRAVERSAL_DONE; fi(PF_SP, tid) = 0;
+#if defined(RT_POOL_DEBUG)
+    s_src[4 + tid] = 0; // s_owner
+#endif
+    if (tid == 0) {
+        s_src[0] = (int) blockIdx.x; s_src[1] = 0;
+        s_src[2] = blockIdx.x < a.n_segments ? (int) (a.seg_count[inq][blockIdx.x] & SEG_FILL_MASK) : 0;
+    }
+    if (blockIdx.x == 0 && wave == 0) { // ray statistics: one wave sums the segment counts of this launch
+        u32 sum = 0;
+        for (u32 k = lane; k < a.n_segments; k += 64u) sum += a.seg_count[inq][k] & SEG_FILL_MASK;
+        sum = wave_sum(sum);
+        if (lane == 0) atomicAdd(a.probe ? &a.stats->rays_probe : &a.stats->rays_camera, (unsigned long long) sum);
+    }
+    // leaves the instance a ray has finished: the world-space box-test constants come back, the marker is popped
+    auto leave_instance = [&](u32 slot, PoolStack& st, int& cur, u32& kzw) {
+        u32 qi = (u32) fi(PF_QI, slot);
+        RT_POOL_CHECK(qi < a.n_paths, 7, qi, qi = 0)
+        const float4 s0 = side[qi], s1 = side[(size_t) a.n_paths + qi], s2 = side[2 * (size_t) a.n_paths + qi];
+        ff(PF_IDX, slot) = s0.x; ff(PF_IDY, slot) = s0.y; ff(PF_IDZ, slot) = s0.z; ff(PF_CNX, slot) = s0.w;
+        ff(PF_CNY, slot) = s1.x; ff(PF_CNZ, slot) = s1.y; ff(PF_CFX, slot) = s1.z; ff(PF_CFY, slot) = s1.w; ff(PF_CFZ, slot) = s2.x;
+        const unsigned long long tn = (unsigned long long) sc.tlas_nodes;
+        fi(PF_NLO, slot) = (int) (u32) tn; fi(PF_NHI, slot) = (int) (u32) (tn >> 32);
+        kzw &= ~0x100u; fi(PF_KZ, slot) = (int) kzw;
+        cur = st.pop();
+    };
+#if defined(RT_POOL_DEBUG)
+    u32 rounds = 0;
+#endif
+    for (;;) {
+#if defined(RT_POOL_DEBUG)
+        if (++rounds > 2000000u) { if (tid == 0) { RT_POOL_CHECK(false, 9, blockIdx.x, ) } break; } // uniform
+#endif
+        // ---- 1. what every ray of the pool needs next --------------------------------------------------------------------
+        pool_barrier(); // the phases of the round before have stored their rays
+        const int c = fi(PF_CLS, tid);
+        const bool pend = c == PC_FREE && fi(PF_QI, tid) >= 0;
+        unsigned long long m[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) m[k] = __ballot(c == k);
+        const unsigned long long mp = __ballot(pend);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) s_wc[k * 4 + wave] = __popcll(m[k]);
+            s_wc[16 + wave] = mp != 0ull ? 1 : 0;
+        }
+        if (tid == 0) { // the segment in hand is used up: on to this workgroup's next one that holds rays
+            int seg = s_src[0], pos = s_src[1], fill = s_src[2];
+            while (pos >= fill && (u32) seg < a.n_segments) {
+                seg += (int) seg_stride; pos = 0;
+                fill = (u32) seg < a.n_segments ? (int) (a.seg_count[inq][seg] & SEG_FILL_MASK) : 0;
+            }
+            s_src[0] = seg; s_src[1] = pos; s_src[2] = fill;
+        }
+        pool_barrier();
+        // ---- 2. lists of slots by class (rank = rays of the class in the waves before + in the lanes before) ---------------
+        int n[4], base[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            n[k] = 0; base[k] = 0;
+#pragma unroll
+            for (u32 w = 0; w < 4; w++) { const int v = s_wc[k * 4 + w]; if (w < wave) base[k] += v; n[k] += v; }
+        }
+        const bool any_pend = (s_wc[16] | s_wc[17] | s_wc[18] | s_wc[19]) != 0;
+        const int seg = s_src[0], pos = s_src[1], fill = s_src[2];
+        if (c < 4) {
+            const unsigned long long mine = m[c];
+            const int rank = base[c] + (int) __builtin_amdgcn_mbcnt_hi((u32) (mine >> 32), __builtin_amdgcn_mbcnt_lo((u32) mine, 0u));
+            s_list[c * POOL_RAYS + rank] = (int) tid;
+        }
+        const int avail = fill - pos; // > 0 unless the queue is used up (step 1 moved on otherwise)
+        if (!(avail > 0 || any_pend)) n[PC_FREE] = 0; // nothing to write, nothing to take: the free slots stay as they are
+        if (n[0] + n[1] + n[2] + n[3] == 0) break; // uniform: every ray is done and written
+        pool_barrier();
+        // ---- 3. batches: the full ones of every class first, then the partial ones by size; wave w takes the w-th ----------
+        int b_cls = -1, b_first = 0, b_cnt = 0, free_taken = 0;
+        {
+            int nb[4], rem[4], total_full = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { nb[k] = n[k] >> 6; rem[k] = n[k] & 63; total_full += nb[k]; }
+            int key[4]; // partial batches, largest first: (size, class)
+#pragma unroll
+            for (int k = 0; k < 4; k++) key[k] = (rem[k] << 2) | k;
+#define RT_POOL_CSWAP(i, j) { const int lo_ = key[i] < key[j] ? key[i] : key[j], hi_ = key[i] < key[j] ? key[j] : key[i]; key[i] = hi_; key[j] = lo_; }
+            RT_POOL_CSWAP(0, 1) RT_POOL_CSWAP(2, 3) RT_POOL_CSWAP(0, 2) RT_POOL_CSWAP(1, 3) RT_POOL_CSWAP(1, 2)
+#undef RT_POOL_CSWAP
+#pragma unroll
+            for (int w = 0; w < 4; w++) { // the batch of wave w (every wave works out all four: the FREE batches of the round decide how many rays the queue hands out)
+                int cls = -1, first = 0, count = 0;
+                if (w < total_full) {
+                    int j = w;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { if (cls < 0 && j < nb[k]) { cls = k; first = j * 64; count = 64; } j -= nb[k]; }
+                } else {
+                    const int kk = key[(w - total_full) & 3];
+                    if ((w - total_full) < 4 && (kk >> 2) > 0) { cls = kk & 3; first = nb[cls] * 64; count = kk >> 2; }
+                }
+                if (cls == PC_FREE) free_taken += count;
+                if (w == (int) wave) { b_cls = cls; b_first = first; b_cnt = count; }
+            }
+        }
+        b_cls = __builtin_amdgcn_readfirstlane(b_cls); b_first = __builtin_amdgcn_readfirstlane(b_first); b_cnt = __builtin_amdgcn_readfirstlane(b_cnt);
+        const bool valid = (int) lane < b_cnt;
+        const u32 slot = valid ? (u32) s_list[(b_cls < 0 ? 0 : b_cls) * POOL_RAYS + b_first + (int) lane] : 0u;
+#if defined(RT_POOL_DEBUG)
+        if (valid) { // every slot belongs to one batch of the round, and its class is the batch's
+            RT_LDS int* const s_owner = s_src + 4;
+            const int prev = atomicExch((int*) &s_owner[slot], (int) rounds);
+            const int cls_now = fi(PF_CLS, slot);
+            if (prev == (int) rounds || cls_now != b_cls || slot >= (u32) POOL_RAYS) {
+                if (atomicCAS(&a.stats->pool_err[0], 0ull, prev == (int) rounds ? 11ull : 12ull) == 0ull) {
+                    a.stats->pool_err[1] = slot; a.stats->pool_err[2] = (unsigned long long) b_cls; a.stats->pool_err[3] = (unsigned long long) cls_now;
+                    a.stats->pool_err[4] = ((unsigned long long) wave << 32) | lane; a.stats->pool_err[5] = ((unsigned long long) b_first << 32) | (u32) b_cnt;
+                    a.stats->pool_err[6] = rounds; a.stats->pool_err[7] = ((unsigned long long) n[0] << 48) | ((unsigned long long) n[1] << 32) | ((unsigned long long) n[2] << 16) | (unsigned long long) n[3];
+                }
+            }
+        }
+#endif
+        // ---- 4. the wave's batch ---------------------------------------------------------------------------------------
+        if (b_cls == PC_NODE) {
+            int cur = RT_TRAVERSAL_DONE; u32 kzw = 0; float best_t = 0.0f;
+            PoolStack st; st.lds = s_stack + slot; st.sp = 0;
+            BoxRay br; br.idx = br.idy = br.idz = 1.0f; br.cnx = br.cny = br.cnz = 0.0f; br.cfx = br.cfy = br.cfz = 0.0f; br.px = br.py = br.pz = true;
+            const RT_GLOBAL PackedNode* nodes = nullptr;
+            if (valid) {
+                cur = fi(PF_CUR, slot); st.sp = fi(PF_SP, slot); kzw = (u32) fi(PF_KZ, slot); best_t = ff(PF_T, slot);
+                br.idx = ff(PF_IDX, slot); br.idy = ff(PF_IDY, slot); br.idz = ff(PF_IDZ, slot);
+                br.cnx = ff(PF_CNX, slot); br.cny = ff(PF_CNY, slot); br.cnz = ff(PF_CNZ, slot);
+                br.cfx = ff(PF_CFX, slot); br.cfy = ff(PF_CFY, slot); br.cfz = ff(PF_CFZ, slot);
+                br.px = br.idx >= 0.0f; br.py = br.idy >= 0.0f; br.pz = br.idz >= 0.0f;
+                nodes = (const RT_GLOBAL PackedNode*) (((unsigned long long) (u32) fi(PF_NHI, slot) << 32) | (u32) fi(PF_NLO, slot));
+            }
+            // steps down the tree while at least half of the batch still holds inner nodes: the rest wait with their leaf (or
+            // their end) in hand, and go back to the pool with the others
+            for (int steps = 0; steps < POOL_NODE_STEPS_MAX; steps++) {
+                const bool inner = valid && cur >= 0;
+                const int ni = __popcll(__ballot(inner));
+                if (ni == 0 || (steps > 0 && 2 * ni < b_cnt)) break;
+#if defined(RT_POOL_DEBUG)
+                if (inner) {
+                    const unsigned long long adr = (unsigned long long) nodes + ((unsigned long long) (u32) cur << 4);
+                    const bool top_ok = (kzw & 0x100u) == 0u && nodes == (const RT_GLOBAL PackedNode*) sc.tlas_nodes && ((unsigned long long) (u32) cur << 4) + 32ull <= a.dbg_tlas_bytes;
+                    const bool bot_ok = (kzw & 0x100u) != 0u && adr >= a.dbg_blas_lo && adr + 32ull <= a.dbg_blas_hi;
+                    RT_POOL_CHECK(top_ok || bot_ok, 1, adr, cur = RT_TRAVERSAL_DONE)
+                    RT_POOL_CHECK(st.sp >= 0 && st.sp + 1 < ROWS, 2, st.sp, cur = RT_TRAVERSAL_DONE)
+                }
+                if (valid && cur >= 0)
+#else
+                if (inner)
+#endif
+                    cur = node_step<PoolStack, COUNT>(nodes, br, cur, a.tmin, best_t, st, cnt);
+            }
+            if (valid) {
+                if (cur == RT_STACK_MARKER) leave_instance(slot, st, cur, kzw);
+                fi(PF_CUR, slot) = cur; fi(PF_SP, slot) = st.sp; fi(PF_CLS, slot) = pool_class_of(cur, (kzw & 0x100u) != 0u);
+            }
+        } else if (b_cls == PC_LEAF) {
+            if (valid) {
+                int cur = fi(PF_CUR, slot); u32 kzw = (u32) fi(PF_KZ, slot);
+                PoolStack st; st.lds = s_stack + slot; st.sp = fi(PF_SP, slot);
+                RayPrep rp;
+                rp.o = mk3(ff(PF_OX, slot), ff(PF_OY, slot), ff(PF_OZ, slot)); rp.sx = ff(PF_SX, slot); rp.sy = ff(PF_SY, slot); rp.sz = ff(PF_SZ, slot);
+                rp.kz = (int) (kzw & 3u); rp.flip = kzw & 0x80000000u;
+                ClosestHit ch;
+                ch.t = ff(PF_T, slot); ch.u_num = ff(PF_UN, slot); ch.v_num = ff(PF_VN, slot); ch.det = ff(PF_DET, slot);
+                ch.inst = fi(PF_INST, slot); ch.tri = fi(PF_TRI, slot); ch.prim_global = (u32) fi(PF_PRIM, slot);
+                const RT_GLOBAL TriRec* tris = (const RT_GLOBAL TriRec*) (((unsigned long long) (u32) fi(PF_THI, slot) << 32) | (u32) fi(PF_TLO, slot));
+                const int cinst = fi(PF_CINST, slot);
+                const float t_before = ch.t; const int tri_before = ch.tri, inst_before = ch.inst;
+                const int v = ~cur, first = v >> 3;
+                int count = (v & 7) + 1;
+#if defined(RT_POOL_DEBUG)
+                {
+                    const unsigned long long adr = (unsigned long long) (tris + first);
+                    if (!(adr >= a.dbg_blas_lo && adr + 48ull * (unsigned long long) count <= a.dbg_blas_hi && (kzw & 0x100u) != 0u)) {
+                        if (atomicCAS(&a.stats->pool_err[0], 0ull, 3ull) == 0ull) {
+                            a.stats->pool_err[1] = adr; a.stats->pool_err[2] = (unsigned long long) (u32) cur; a.stats->pool_err[3] = kzw;
+                            a.stats->pool_err[4] = (unsigned long long) tris; a.stats->pool_err[5] = (unsigned long long) (u32) cinst;
+                            a.stats->pool_err[6] = (unsigned long long) (u32) st.sp; a.stats->pool_err[7] = ((unsigned long long) slot << 32) | (u32) fi(PF_QI, slot);
+                        }
+                        count = 0;
+                    }
+                    RT_POOL_CHECK(st.sp >= 0 && st.sp < ROWS, 4, st.sp, st.sp = 0)
+                }
+#endif
+                for (int k = 0; k < count; k++) {
+                    const RT_GLOBAL TriRec* tr = tris + first + k;
+                    const Quad qa = ldq(tr, 0), qb = ldq(tr, 1), qc = ldq(tr, 2);
+                    if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
+                    triangle_candidate(rp, mk3(qa.x, qa.y, qa.z), mk3(qa.w, qb.x, qb.y), mk3(qb.z, qb.w, qc.x), a.tmin, cinst, first + k, as_u32(qc.y), ch);
+                }
+                if (ch.t != t_before || ch.tri != tri_before || ch.inst != inst_before) {
+                    ff(PF_T, slot) = ch.t; ff(PF_UN, slot) = ch.u_num; ff(PF_VN, slot) = ch.v_num; ff(PF_DET, slot) = ch.det;
+                    fi(PF_INST, slot) = ch.inst; fi(PF_TRI, slot) = ch.tri; fi(PF_PRIM, slot) = (int) ch.prim_global;
+                }
+                cur = st.pop();
+                if (cur == RT_STACK_MARKER) leave_instance(slot, st, cur, kzw);
+                fi(PF_CUR, slot) = cur; fi(PF_SP, slot) = st.sp; fi(PF_CLS, slot) = pool_class_of(cur, (kzw & 0x100u) != 0u);
+            }
+        } else if (b_cls == PC_INST) {
+            if (valid) { // a top-level leaf: into the instance (trace_bottom_level)
+                const int p = ~fi(PF_CUR, slot);
+                int cinst = p == sc.inl_inst ? (int) sc.n_insts - 1 : p; // the slot of the inlined instance holds the last one (SceneView)
+                u32 qi = (u32) fi(PF_QI, slot);
+                RT_POOL_CHECK((u32) cinst < sc.n_insts, 5, cinst, cinst = 0)
+                RT_POOL_CHECK(qi < a.n_paths, 6, qi, qi = 0)
+                PoolStack st; st.lds = s_stack + slot; st.sp = fi(PF_SP, slot);
+                if (COUNT) { cnt.insts++; if (first_active_lane()) cnt.inst_trips++; }
+                const RayQueue& q = a.q[inq];
+                const f3 o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]), d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
+                const RT_GLOBAL InstRec* in = (const RT_GLOBAL InstRec*) sc.insts + cinst;
+                const Quad m0 = ldq(in, 0), m1 = ldq(in, 1), m2 = ldq(in, 2), m3 = ldq(in, 3), m4 = ldq(in, 4), m5 = ldq(in, 5);
+                const float w2o[12] = { m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w };
+                const f3 oo = xform_point43(w2o, o), od = xform_dir43(w2o, d);
+                const RayPrep rp = prepare_ray(oo, od);
+                const unsigned long long pn = ((unsigned long long) as_u32(m3.y) << 32) | as_u32(m3.x);
+                const unsigned long long pt = pn + as_u32(m3.z) + (unsigned long long) ((u32) rp.kz * as_u32(m5.z)); // the triangle copy of this ray's kz
+                const BoxRay br = make_box_ray(oo, od, m3.w, mk3(m4.x, m4.y, m4.z), mk3(m4.w, m5.x, m5.y));
+                ff(PF_IDX, slot) = br.idx; ff(PF_IDY, slot) = br.idy; ff(PF_IDZ, slot) = br.idz;
+                ff(PF_CNX, slot) = br.cnx; ff(PF_CNY, slot) = br.cny; ff(PF_CNZ, slot) = br.cnz;
+                ff(PF_CFX, slot) = br.cfx; ff(PF_CFY, slot) = br.cfy; ff(PF_CFZ, slot) = br.cfz;
+                ff(PF_OX, slot) = rp.o.x; ff(PF_OY, slot) = rp.o.y; ff(PF_OZ, slot) = rp.o.z;
+                ff(PF_SX, slot) = rp.sx; ff(PF_SY, slot) = rp.sy; ff(PF_SZ, slot) = rp.sz;
+                fi(PF_KZ, slot) = (int) ((u32) rp.kz | rp.flip | 0x100u);
+                fi(PF_NLO, slot) = (int) (u32) pn; fi(PF_NHI, slot) = (int) (u32) (pn >> 32);
+                fi(PF_TLO, slot) = (int) (u32) pt; fi(PF_THI, slot) = (int) (u32) (pt >> 32);
+                fi(PF_CINST, slot) = cinst;
+                st.push(RT_STACK_MARKER);
+                fi(PF_CUR, slot) = 0; fi(PF_SP, slot) = st.sp; fi(PF_CLS, slot) = PC_NODE;
+            }
+        } else if (b_cls == PC_FREE) {
+            if (valid) {
+                // the ray that held the slot is finished: its hit record (as k_traverse writes it for two-level scenes)
+                int qold = fi(PF_QI, slot);
+                RT_POOL_CHECK(qold < (int) a.n_paths, 8, qold, qold = -1)
+                if (qold >= 0) {
+                    const int inst = fi(PF_INST, slot);
+                    float t = inf_f32(), u = 0.0f, v = 0.0f;
+                    if (inst >= 0) { const float det = ff(PF_DET, slot); t = ff(PF_T, slot); u = ff(PF_UN, slot) / det; v = ff(PF_VN, slot) / det; } // S4: u = V / det, v = W / det
+                    ((float4*) a.hits.t)[qold] = make_float4(t, u, v, __int_as_float(inst));
+                    if (inst >= 0) a.hits.tri[qold] = fi(PF_TRI, slot);
+                }
+            }
+            // the next rays of the queue segment, one per free slot in list order
+            const int idx = pos + b_first + (int) lane;
+            const bool take = valid && idx < fill;
+            if (take) {
+                u32 qi = (u32) seg * SEG + (u32) idx;
+                RT_POOL_CHECK(qi < a.n_paths && (u32) seg < a.n_segments, 10, qi, qi = 0)
+                const RayQueue& q = a.q[inq];
+                const f3 o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]), d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
+                const BoxRay br = make_box_ray(o, d, sc.tlas_bound, mk3(sc.tlas_ctr[0], sc.tlas_ctr[1], sc.tlas_ctr[2]), mk3(sc.tlas_inv_h[0], sc.tlas_inv_h[1], sc.tlas_inv_h[2]));
+                side[qi] = make_float4(br.idx, br.idy, br.idz, br.cnx);
+                side[(size_t) a.n_paths + qi] = make_float4(br.cny, br.cnz, br.cfx, br.cfy);
+                side[2 * (size_t) a.n_paths + qi] = make_float4(br.cfz, 0.0f, 0.0f, 0.0f);
+                ff(PF_IDX, slot) = br.idx; ff(PF_IDY, slot) = br.idy; ff(PF_IDZ, slot) = br.idz;
+                ff(PF_CNX, slot) = br.cnx; ff(PF_CNY, slot) = br.cny; ff(PF_CNZ, slot) = br.cnz;
+                ff(PF_CFX, slot) = br.cfx; ff(PF_CFY, slot) = br.cfy; ff(PF_CFZ, slot) = br.cfz;
+                const unsigned long long tn = (unsigned long long) sc.tlas_nodes;
+                fi(PF_NLO, slot) = (int) (u32) tn; fi(PF_NHI, slot) = (int) (u32) (tn >> 32);
+                fi(PF_KZ, slot) = 0; fi(PF_QI, slot) = (int) qi;
+                ClosestHit ch; ch.t = a.tmax; ch.u_num = 0.0f; ch.v_num = 0.0f; ch.det = 1.0f; ch.inst = -1; ch.tri = -1; ch.prim_global = 0;
+                // NaN or infinite rays miss without a walk (trace_begin)
+                const float big = 3.0e38f;
+                const bool finite = fabsf(o.x) <= big && fabsf(o.y) <= big && fabsf(o.z) <= big && fabsf(d.x) <= big && fabsf(d.y) <= big && fabsf(d.z) <= big;
+                int cur = finite ? 0 : RT_TRAVERSAL_DONE;
+                if (sc.inl_inst >= 0 && finite) { // the triangles of the inlined instance first (SceneView::inl_inst)
+                    inlined_triangles_first<COUNT>(sc, o, d, a.tmin, sc.inl_inst, ch, cnt);
+                    if (sc.n_insts < 2u) cur = RT_TRAVERSAL_DONE;
+                }
+                ff(PF_T, slot) = ch.t; ff(PF_UN, slot) = ch.u_num; ff(PF_VN, slot) = ch.v_num; ff(PF_DET, slot) = ch.det;
+                fi(PF_INST, slot) = ch.inst; fi(PF_TRI, slot) = ch.tri; fi(PF_PRIM, slot) = (int) ch.prim_global;
+                fi(PF_CUR, slot) = cur; fi(PF_SP, slot) = 0; fi(PF_CLS, slot) = pool_class_of(cur, false);
+            } else if (valid) {
+                fi(PF_QI, slot) = -1; // written, and no ray to take in this round
+                fi(PF_CLS, slot) = avail > 0 ? PC_FREE : PC_IDLE; // (a segment may end inside a batch: the slot asks again)
+            }
+        }
+        if (tid == 0) s_src[1] = pos + (free_taken < avail ? free_taken : (avail > 0 ? avail : 0)); // rays handed out in this round
+    }
+    if (COUNT) traverse_counters_flush(a, cnt);
 }
 
 // ---- hit / miss shaders + the tail of the trace_path_sample loop body (raytracing.hlsl:113-119) ------------------
@@ -1145,7 +1470,27 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
     const u32 n_tasks = grid.x;
     // 6 waves per SIMD = 80 VGPRs = what the LDS stacks allow as well (6.5 KB per wave); the persistent variant keeps 5 (it needs 96)
     const bool persistent = a.persistent_slots != 0 && !count_traversal && (primary ? (a.persistent & 2u) != 0 : (a.persistent & 1u) != 0) && n_tasks > a.persistent_slots;
-    if (persistent) {
+    if (!primary && !persistent && a.pool_groups != 0u && a.scene.flat_instances == 0u && a.stack_in_lds != 0u) {
+        // two-level scenes, queued rays: pooled traversal (rt_dev_pool.h), one persistent workgroup per 256-ray pool
+        const int rows = a.stack_in_lds == 2u ? 33 : 17;
+#if defined(RT_POOL_DEBUG)
+        const size_t lds = ((size_t) (rows + PF_COUNT + 5) * POOL_RAYS + 32) * sizeof(int);
+#else
+        const size_t lds = ((size_t) (rows + PF_COUNT + 4) * POOL_RAYS + 24) * sizeof(int);
+#endif
+        const void* fn = count_traversal ? (rows == 33 ? (const void*) k_traverse_pool<true, 33> : (const void*) k_traverse_pool<true, 17>)
+                                         : (rows == 33 ? (const void*) k_traverse_pool<false, 33> : (const void*) k_traverse_pool<false, 17>);
+        RT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+#if defined(RT_POOL_DEBUG)
+        RT_HIP(hipMemsetAsync(a.hits.t, 0xff, 16 * (size_t) a.n_paths, s)); // a hit record the kernel fails to write reads as a miss (id -1) in k_shade
+#endif
+        const u32 groups = a.pool_groups < a.n_segments ? a.pool_groups : a.n_segments;
+        dim3 pgrid(groups), pblock(POOL_RAYS);
+        if (count_traversal) { if (rows == 33) hipLaunchKernelGGL((k_traverse_pool<true, 33>), pgrid, pblock, lds, s, a, in_queue);
+                               else hipLaunchKernelGGL((k_traverse_pool<true, 17>), pgrid, pblock, lds, s, a, in_queue); }
+        else if (rows == 33) hipLaunchKernelGGL((k_traverse_pool<false, 33>), pgrid, pblock, lds, s, a, in_queue);
+        else hipLaunchKernelGGL((k_traverse_pool<false, 17>), pgrid, pblock, lds, s, a, in_queue);
+    } else if (persistent) {
         dim3 pgrid(a.persistent_slots);
         if (primary) hipLaunchKernelGGL((k_traverse<false, 5, true, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
         else hipLaunchKernelGGL((k_traverse<false, 5, false, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);

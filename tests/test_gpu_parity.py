@@ -110,6 +110,19 @@ def test_many_instances_of_tiny_blas(oracle_mod):
     _check_scene(s, oracle_mod, frames=1, brute_force=True)
 
 
+@pytest.mark.parametrize("pool", ["0", "2"])
+def test_pooled_and_per_lane_traversal_agree_with_the_oracle(oracle_mod, monkeypatch, pool):
+    """queued rays of two-level scenes are walked by pools of 256 rays per workgroup that are re-sorted by what they need
+    next (RT_POOL=2: rt_dev_pool.h) or one ray per lane to the end (RT_POOL=0, the default): the closest hit does not depend on
+    the order of the walk (S5), so both give the oracle's ids, t, u, v and RNG streams bit for bit.  Shallow trees (17 stack
+    rows) and deep ones (33), with and without the inlined instance, several frames so that pools see ragged segments."""
+    monkeypatch.setenv("RT_POOL", pool)       # read at rt_create
+    _check_scene(scenes.bunny_field(160, 90, spp=1, bounces=3, grid=20, count=300), oracle_mod, frames=2, brute_force=False)
+    _check_scene(scenes.bunny_field(96, 54, spp=2, bounces=2, grid=8, count=40), oracle_mod, brute_force=False)
+    monkeypatch.setenv("RT_INLINE", "0")
+    _check_scene(scenes.bunny_field(128, 72, spp=1, bounces=2, grid=8, count=50), oracle_mod, brute_force=False)
+
+
 @pytest.mark.parametrize("builder", ["0", "1", "2", "3", "4"])
 def test_every_bvh_builder_gives_the_same_hits(oracle_mod, monkeypatch, builder):
     """the closest hit does not depend on the tree (S5): Karras LBVH (0), PLOC (1), binned SAH (2), the
