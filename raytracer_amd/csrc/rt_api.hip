@@ -126,6 +126,8 @@ struct rt_ctx {
     bool render_target_stale = false; u32 render_target_frames = 0;
     // BSSRDF tables
     float* d_table[2] = { nullptr, nullptr }; int table_texels[2] = { 0, 0 }; int profile = 0;
+    // differences of consecutive scaled texels for k_gather<3> (ensure_gather_delta): valid for (table, factor) below
+    float4* d_gather_delta = nullptr; const float* delta_table = nullptr; float delta_factor = 0.0f; int delta_texels = 0; int gather_l1 = 0; /* RT_GATHER_L1=1: measured, not kept (profiles/r03_ab_gather_l1.txt) */
     // stats
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, timed_primary, timed_gather; double traverse_ms = 0, traverse_primary_ms = 0, gather_ms = 0;
     uint64_t traverse_launches = 0, gather_launches = 0, primary_rays = 0, traverse_launches_timed = 0, gather_launches_timed = 0;
@@ -343,6 +345,8 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.hg.order = c->d_hg_order; a.hg.slices = c->d_hg_slices; a.hg.max_solid_angle = c->hg_max_solid_angle;
     a.hg.enabled = (c->hg_enabled && c->hg_built) ? 1u : 0u;
     a.bssrdf_table = c->d_table[c->profile]; a.bssrdf_texels = c->table_texels[c->profile];
+    a.gather_delta = (c->gather_l1 && c->d_gather_delta && c->delta_table == a.bssrdf_table && c->delta_texels == a.bssrdf_texels &&
+                      c->delta_factor == a.fudge / (c->g.translucent_bssrdf_scale * c->g.translucent_bssrdf_scale)) ? c->d_gather_delta : nullptr;
 }
 
 // pixels of this rank's tiles that lie inside the image
@@ -664,6 +668,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_RAY_SORT")) c->ray_sort = atoi(v);
     if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
     if (const char* v = getenv("RT_POOL")) c->pool = atoi(v);
+    if (const char* v = getenv("RT_GATHER_L1")) c->gather_l1 = atoi(v);
     if (const char* v = getenv("RT_XCD_BANDS")) c->xcd_bands = atoi(v);
     if (const char* v = getenv("RT_SORT_BOX")) c->sort_box = atoi(v);
     if (const char* v = getenv("RT_SORT_CHORD")) c->sort_chord_pct = (float) atof(v);
@@ -726,7 +731,7 @@ void rt_destroy(rt_ctx* c) {
     free_flat_tree(c);
     dev_free(c->d_task_counter);
     dev_free(c->d_accumulator); dev_free(c->d_render_target); dev_free(c->d_capture); dev_free(c->d_arena);
-    dev_free(c->d_seg_count); dev_free(c->d_stats); dev_free(c->d_table[0]); dev_free(c->d_table[1]);
+    dev_free(c->d_seg_count); dev_free(c->d_stats); dev_free(c->d_table[0]); dev_free(c->d_table[1]); dev_free(c->d_gather_delta);
     lbvh_workspace_free(c->lbvh); ploc_workspace_free(c->ploc); sah_workspace_free(c->sah);
     for (int k = 0; k < 2; k++) if (c->build_ev[k]) (void) hipEventDestroy(c->build_ev[k]);
     if (c->own_stream) (void) hipStreamDestroy(c->own_stream);
@@ -766,6 +771,7 @@ int rt_load_bssrdf_table(rt_ctx* c, int profile, const float* r, const float* g,
     for (u32 i = 0; i < n; i++) { t[3 * i] = r[i]; t[3 * i + 1] = g[i]; t[3 * i + 2] = b[i]; }
     RT_HIP(hipStreamSynchronize(c->stream));
     dev_free(c->d_table[profile]);
+    c->delta_table = nullptr; // (a new table may get the old one's address)
     RT_HIP(hipMalloc(&c->d_table[profile], t.size() * 4));
     RT_HIP(hipMemcpy(c->d_table[profile], t.data(), t.size() * 4, hipMemcpyHostToDevice));
     c->table_texels[profile] = (int) padded;
@@ -1226,9 +1232,29 @@ int dispatch_serial(rt_ctx* c) {
 }
 } // namespace
 
+namespace {
+// the table of texel differences k_gather<3> reads belongs to one (profile table, fudge / scale^2) pair: rebuilt when the
+// globals or the profile change, with nothing in flight (both lanes may be reading the old one)
+int ensure_gather_delta(rt_ctx* c) {
+    const float scale = c->g.translucent_bssrdf_scale;
+    const float* table = c->d_table[c->profile]; const int n = c->table_texels[c->profile];
+    if (!c->gather_l1 || scale == 0.0f || !table || n > 2048 || c->n_points == 0) return RT_OK;
+    const float factor = ((c->flags & RT_FLAG_ENABLE_SSS) ? c->g.translucent_bssrdf_fudge : 0.0f) / (scale * scale);
+    if (c->d_gather_delta && c->delta_table == table && c->delta_texels == n && c->delta_factor == factor) return RT_OK;
+    { int rc = quiesce(c); if (rc) return rc; }
+    RT_HIP(hipStreamSynchronize(c->stream));
+    if (!c->d_gather_delta) RT_HIP(hipMalloc(&c->d_gather_delta, sizeof(float4) * (2048 + 4)));
+    int rc = launch_gather_delta(c->stream, table, n, factor, c->d_gather_delta); if (rc) return rc;
+    RT_HIP(hipStreamSynchronize(c->stream));
+    c->delta_table = table; c->delta_texels = n; c->delta_factor = factor;
+    return RT_OK;
+}
+} // namespace
+
 int rt_dispatch_rays(rt_ctx* c) {
     { int vrc = validate_dispatch(c); if (vrc) return vrc; }
     RT_HIP(hipSetDevice(c->device));
+    { int grc = ensure_gather_delta(c); if (grc) return grc; }
     bool collect = (c->flags & RT_FLAG_COLLECT_SAMPLES) && c->n_points > 0;
     const bool gather = c->n_points > 0 && (c->flags & RT_FLAG_ENABLE_SSS) && c->g.translucent_bssrdf_fudge != 0.0f;
     // Frames are pipelined over the two lanes.  A frame touches its lane's path buffers and copy of the sample points,

@@ -187,6 +187,7 @@ struct PassArgs {
     const u32* sp_slice;         // per point -> slice index
     u32 n_points;
     HgView hg;
+    const float4* gather_delta;  // k_gather<3>: differences of consecutive scaled texels, fetched through L1 (launch_gather_delta); null: both texels from LDS
     const float* bssrdf_table;   // rgb interleaved
     int bssrdf_texels;
 };
@@ -197,6 +198,7 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
 // fused: finished camera paths resolve their pixel in the shade kernel (no launch_camera_resolve afterwards)
 int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index, bool primary, bool fused);
 int launch_gather(hipStream_t s, const PassArgs& a);
+int launch_gather_delta(hipStream_t s, const float* table, int n, float factor, float4* delta);
 int launch_sort_payload(hipStream_t s, const RtSamplePoint* src, const u32* order, const u32* slice_of, const rtd::TranslucentSlice* slices, u32 n, float4* pay);
 int launch_hg_sums(hipStream_t s, const PassArgs& a, u32 n_slices); // refresh HgView::pay / sums from sp_read
 int launch_camera_resolve(hipStream_t s, const PassArgs& a);

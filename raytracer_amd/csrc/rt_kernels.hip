@@ -1070,6 +1070,35 @@ RT_DEV f3 sample_bssrdf_table_lds(const float4* tab, int n, float u) {
     const float4 t0 = tab[k0], t1 = tab[k0 + 1];
     return mk3(__builtin_fmaf(f, t1.x - t0.x, t0.x), __builtin_fmaf(f, t1.y - t0.y, t0.y), __builtin_fmaf(f, t1.z - t0.z, t0.z));
 }
+// The same value with the second fetch taken off the LDS pipe: the difference to the next texel comes from a table in global
+// memory (k_gather_delta: the same scaled texels, subtracted once instead of per pair) through the vector L1.  The LDS pipe
+// is shared by the four SIMDs of a CU and spends half its active cycles on the bank conflicts of these per-lane fetches
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.53, profiles/pmc_traffic.json c4), the texture path idles (TA busy 0.02).
+RT_DEV f3 sample_bssrdf_table_lds_l1(const float4* tab, const float4* __restrict__ delta, int n, float u) {
+    const float x = u * (float) n - 0.5f;
+    const float fl = floorf(x);
+    const float f = x - fl;
+    const int k0 = (int) fminf(fmaxf(fl, -2.0f), (float) n) + 2; // 0 .. n + 2
+    const float4 t0 = tab[k0], dt = delta[k0];
+    return mk3(__builtin_fmaf(f, dt.x, t0.x), __builtin_fmaf(f, dt.y, t0.y), __builtin_fmaf(f, dt.z, t0.z));
+}
+// delta[t] = entry t + 1 - entry t of the table as tab_fill_lds lays it out (scaled texels, zero border), t = 0 .. n + 3
+__global__ void k_gather_delta(const float* __restrict__ table, int n, float factor, float4* __restrict__ delta) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n + 4) return;
+    float e0[3], e1[3];
+    for (int c = 0; c < 3; c++) {
+        const int k0 = t - 2, k1 = t - 1;
+        e0[c] = (k0 >= 0 && k0 < n) ? factor * table[3 * k0 + c] : 0.0f;
+        e1[c] = (k1 >= 0 && k1 < n) ? factor * table[3 * k1 + c] : 0.0f;
+    }
+    delta[t] = make_float4(e1[0] - e0[0], e1[1] - e0[1], e1[2] - e0[2], 0.0f);
+}
+int launch_gather_delta(hipStream_t s, const float* table, int n, float factor, float4* delta) {
+    hipLaunchKernelGGL(k_gather_delta, dim3((n + 4 + 255) / 256), dim3(256), 0, s, table, n, factor, delta);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
 // `factor` (fudge / scale^2, raytracing.hlsl:276) is multiplied into the texels here, once, instead of into every filtered value
 template <int BLOCK>
 RT_DEV void tab_fill_lds(float4* tab, const float* table, int n, float factor) {
@@ -1110,7 +1139,7 @@ __global__ __launch_bounds__(SEG) void k_gather_offsets(PassArgs a) {
 template <int MODE>
 __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
     __shared__ GatherPoint s_pts[MODE == 0 ? GATHER_TILE : 1];
-    __shared__ float4 s_tab[MODE == 1 ? GATHER_TABLE_MAX + 4 : 1];
+    __shared__ float4 s_tab[(MODE == 1 || MODE == 3) ? GATHER_TABLE_MAX + 4 : 1];
     __shared__ int s_next;
     const u32 n_items = a.goff[a.n_segments];
     if (blockIdx.x * GATHER_BLOCK >= n_items) return; // uniform
@@ -1124,7 +1153,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
         i = lo * SEG + (jj - a.goff[lo]);
     }
     const GatherQueue& g = a.gq;
-    if (MODE == 1 && a.sort_box_on == 1u) {
+    if ((MODE == 1 || MODE == 3) && a.sort_box_on == 1u) {
         // The workgroup's items regrouped by the cell of the mesh's box their hit lies in: the hits of a wave then sit
         // together, and more of the far point groups below are far for the whole wave (the skip needs every lane to agree)
         __shared__ u32 s_key[66];
@@ -1161,7 +1190,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
     const f3 hit = mk3(g.hx[i], g.hy[i], g.hz[i]);
     const int my_ti = active ? g.ti[i] : -1;
     const float scale = a.g.translucent_bssrdf_scale;
-    if (MODE == 1)
+    if (MODE == 1 || MODE == 3)
         tab_fill_lds<GATHER_BLOCK>(s_tab, a.bssrdf_table, a.bssrdf_texels, a.fudge / (scale * scale));
     // radiance-only arithmetic (covered by the 1e-4 tolerance): fudge / scale^2 is folded into one
     // factor, and the dipole uses the hardware sqrt / rcp / exp2.  The table coordinate radius / scale stays (all but)
@@ -1271,6 +1300,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
                     if (MODE != 0) {
                         const float coord = div_by_shared(radius, scale, inv_scale);
                         bs = MODE == 1 ? sample_bssrdf_table_lds(s_tab, a.bssrdf_texels, coord)            // :272-276 (the factor is in the LDS texels)
+                           : MODE == 3 ? sample_bssrdf_table_lds_l1(s_tab, a.gather_delta, a.bssrdf_texels, coord)
                                        : fudge_over_z * sample_bssrdf_table(a.bssrdf_table, a.bssrdf_texels, coord);
                     } else if (GREY) { float v = dipole_eval_fast(cr, radius); bs = mk3(v, v, v); }               // :278-301
                     else bs = mk3(dipole_eval_fast(cr, radius), dipole_eval_fast(cg, radius), dipole_eval_fast(cb, radius));
@@ -1284,12 +1314,12 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
                 // 0 * payload leaves the sum as it is -- four points that lie that far from every hit of the wave are skipped
                 // (the squared distances are the ones the terms start from; the cut is 0.1 % and two texels outside the support;
                 // C4 +1.9 %; testing the points in pairs of two instead: +1 %, the tests cost more than the extra skips save)
-                const float cut = MODE == 1 ? scale * ((float) (a.bssrdf_texels + 2) / (float) a.bssrdf_texels) * 1.001f : 0.0f;
+                const float cut = (MODE == 1 || MODE == 3) ? scale * ((float) (a.bssrdf_texels + 2) / (float) a.bssrdf_texels) * 1.001f : 0.0f;
                 const float cut2 = cut * cut;
                 auto dist2 = [&](u32 k) -> float { const const_floats sp = spos + 4u * k; f3 dp = mk3(sp[0], sp[1], sp[2]) - hit; return dot3(dp, dp); };
                 u32 k = 0;
                 for (; k + 4 <= nk; k += 4) {
-                    if (MODE == 1 && __all(fminf(fminf(dist2(k), dist2(k + 1)), fminf(dist2(k + 2), dist2(k + 3))) >= cut2)) continue;
+                    if ((MODE == 1 || MODE == 3) && __all(fminf(fminf(dist2(k), dist2(k + 1)), fminf(dist2(k + 2), dist2(k + 3))) >= cut2)) continue;
                     Term c0 = term(k), c1 = term(k + 1), c2 = term(k + 2), c3 = term(k + 3);
                     add(c0); add(c1); add(c2); add(c3);
                 }
@@ -1561,6 +1591,7 @@ int launch_gather(hipStream_t s, const PassArgs& a) {
         return RT_OK;
     }
     if (a.g.translucent_bssrdf_scale == 0.0f) hipLaunchKernelGGL(k_gather<0>, grid, block, 0, s, a); // raytracing.hlsl:316-320
+    else if (a.bssrdf_texels <= GATHER_TABLE_MAX && a.gather_delta) hipLaunchKernelGGL(k_gather<3>, grid, block, 0, s, a);
     else if (a.bssrdf_texels <= GATHER_TABLE_MAX) hipLaunchKernelGGL(k_gather<1>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(k_gather<2>, grid, block, 0, s, a);
     RT_HIP(hipGetLastError());

@@ -67,3 +67,32 @@ def test_static_dispatch_rejects_what_does_not_fit():
         assert rt.read_accumulator().any()
     finally:
         rt.close()
+
+
+def test_static_dispatch_allocates_nothing():
+    """The entry point's promise (include/rt_abi.h): no hipMalloc / hipFree.  Free device memory as the HIP runtime reports it
+    (hipMemGetInfo, asked through the runtime this process already has loaded) is the same before and after a series of
+    static dispatches -- plain camera frames and frames with the sample-point pass and the BSSRDF gather -- once the
+    scene is set up; rt_dispatch_rays on a fresh context, for contrast, takes its path buffers from it."""
+    import ctypes as C
+    from raytracer_amd import api
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    rt = api.Raytracer(0)
+    try:
+        for scene in (scenes.bunny(200, 160, spp=2, bounces=3), scenes.cornell_bunny(160, 120, spp=1, bounces=3, sample_radius=0.05)):
+            scene.setup(rt)
+            _render(rt, scene, True, 1)   # (the runtime's own first-launch set-up -- code objects, kernel-argument pools -- is not the library's)
+            rt.sync()
+            before = free_bytes()
+            _render(rt, scene, True, 4)
+            rt.sync()
+            assert free_bytes() == before, "rt_dispatch_rays_static changed the free device memory"
+    finally:
+        rt.close()

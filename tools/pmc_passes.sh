@@ -1,5 +1,8 @@
 #!/bin/bash
-# usage: tools/pmc_passes.sh <tag> <bench.py args...>   -- one rocprofv3 --pmc run per counter group (csv under gpurun_out/pmc_<tag>_<n>)
+# usage: tools/pmc_passes.sh <tag> <bench.py args...>   -- one rocprofv3 --pmc run per counter group; the per-kernel, per-launch
+# means of all passes end up in gpurun_out/pmc_<tag>.json under the key <tag> (tools/pmc_summary.py; bench.py's pmc_key: the
+# workload, with _WxH unless 1080p), stamped with the hash of the kernel sources; merge into profiles/pmc_traffic.json with
+# tools/pmc_merge.py.  The csv files (tens of MB) stay on the box.
 set -u
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
@@ -20,3 +23,6 @@ for g in "${groups[@]}"; do
   timeout -s KILL 150 rocprofv3 --pmc $g -d gpurun_out/pmc_${tag}_$n -o p --output-format csv -- python3 bench.py --no-cpu --no-alone "$@" > gpurun_out/pmc_${tag}_$n.log 2>&1 || { echo "pass $n failed"; tail -5 gpurun_out/pmc_${tag}_$n.log; exit 1; }
   echo "pass $n ok"
 done
+PMC_SOURCE_HASH=$(cat gpurun_out/pmc_${tag}.hash) python3 tools/pmc_summary.py $tag gpurun_out/pmc_${tag}.json gpurun_out/pmc_${tag}_*/p_counter_collection.csv > gpurun_out/pmc_${tag}.txt || exit 1
+rm -rf gpurun_out/pmc_${tag}_[0-9]*
+echo "summary gpurun_out/pmc_${tag}.json"
