@@ -242,3 +242,28 @@ def test_two_ranks_of_the_product_reproduce_the_one_process_image(split, tmp_pat
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     else:
         assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("workload,split,size", [("c4", "tile", (1920, 1080)), ("c5", "sample", (3840, 2160))])
+def test_the_scale_run_commands_at_baseline_size(workload, split, size, tmp_path):
+    """The exact commands a SCALE run issues for BASELINE.md's C4 (tile split, 1080p, 16 spp) and C5 (sample-set split,
+    4K, all 52,743 instances) rows, rehearsed with two ranks on this box's one GPU (--rehearse: gloo): they run to the
+    end, the line has the fields the driver reads, and the exchange step is the one DESIGN.md section 6 describes --
+    a gather of the owned tiles (1 / N of the frame per rank) for the tile split, a sum of the accumulators otherwise."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90), os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse",
+           "--workload", workload, "--split", split, "--width", str(size[0]), "--height", str(size[1]), "--steps", "2",
+           "--warmup", "1", "--no-cpu"]
+    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["reduce_ms"] > 0 and rec["timed_blocks"] >= 1
+    frame_bytes = size[0] * size[1] * 16
+    if split == "tile":
+        assert rec["scaling"] == "strong" and rec["exchange"]["kind"].startswith("gather")
+        tiles = ((size[0] + 31) // 32) * ((size[1] + 31) // 32)
+        assert rec["exchange"]["bytes_per_rank"] == (tiles + 1) // 2 * 1024 * 16 < 0.51 * frame_bytes   # half of the tiles, not the frame
+    else:
+        assert rec["scaling"] == "weak" and rec["exchange"]["bytes_per_rank"] == frame_bytes
