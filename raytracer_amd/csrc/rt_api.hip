@@ -1403,6 +1403,14 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
         fprintf(stderr, " | blas range 0x%llx..0x%llx tlas bytes %u\n", a.dbg_blas_lo, a.dbg_blas_hi, a.dbg_tlas_bytes);
     }
     else fprintf(stderr, "RT_POOL_DEBUG: no violation\n");
+    if (ds.pool_prof[17]) {
+        const unsigned long long* p = ds.pool_prof; const double w = (double) p[17];
+        fprintf(stderr, "RT_POOL_DEBUG profile over %llu waves: rounds/wave %.0f | cycles per wave: scheduling %.0f barrier-wait %.0f batches NODE %.0f LEAF %.0f INST %.0f FREE %.0f | rounds without a batch %.0f | "
+                        "batches NODE %llu (%.1f rays, %.2f steps) LEAF %llu (%.1f) INST %llu (%.1f) FREE %llu (%.1f)\n",
+                p[17], p[0] / w, p[1] / w, p[2] / w, p[5] / w, p[6] / w, p[7] / w, p[8] / w, p[3] / w,
+                p[9], p[9] ? (double) p[13] / p[9] : 0.0, p[9] ? (double) p[4] / p[9] : 0.0, p[10], p[10] ? (double) p[14] / p[10] : 0.0,
+                p[11], p[11] ? (double) p[15] / p[11] : 0.0, p[12], p[12] ? (double) p[16] / p[12] : 0.0);
+    }
 #endif
     memset(out, 0, sizeof *out);
     out->rays_camera = ds.rays_camera + c->primary_rays; out->rays_probe = ds.rays_probe; out->gather_pairs = ds.gather_pairs;

@@ -133,7 +133,7 @@ struct HgView {
 
 struct DeviceStats { // lives in device memory
     unsigned long long rays_camera, rays_probe, gather_pairs, nodes, tris, insts, node_trips, tri_trips, inst_trips, max_ray_steps;
-    unsigned long long pool_err[8]; // RT_POOL_DEBUG builds: first bounds violation the pooled traversal caught (code, value)
+    unsigned long long pool_err[8]; unsigned long long pool_prof[18]; // (RT_POOL_DEBUG: where the pooled kernel's time goes, summed over waves) // RT_POOL_DEBUG builds: first bounds violation the pooled traversal caught (code, value)
     unsigned long long hg_overflow; // k_gather_hg ran out of walk stack and dropped a subtree: the host reports RT_ERR_LIMIT (rt_sync, rt_get_stats, reads)
 };
 

@@ -563,13 +563,24 @@ __global__ __launch_bounds__(POOL_RAYS, 2) void k_traverse_pool(PassArgs a, u32 
     };
 #if defined(RT_POOL_DEBUG)
     u32 rounds = 0;
+    // where the time goes (lane 0 of every wave): cycles in scheduling (steps 1-3 with their barriers), in the wave's batch, and
+    // waiting at the barrier that ends the round; batches and rays by class
+    unsigned long long prof_sched = 0, prof_batch[4] = { 0, 0, 0, 0 }, prof_wait = 0, prof_nb[4] = { 0, 0, 0, 0 }, prof_nr[4] = { 0, 0, 0, 0 }, prof_idle = 0, prof_steps = 0;
+    unsigned long long t_mark = __builtin_amdgcn_s_memtime();
 #endif
     for (;;) {
 #if defined(RT_POOL_DEBUG)
         if (++rounds > 2000000u) { if (tid == 0) { RT_POOL_CHECK(false, 9, blockIdx.x, ) } break; } // uniform
 #endif
         // ---- 1. what every ray of the pool needs next --------------------------------------------------------------------
+#if defined(RT_POOL_DEBUG)
+        { const unsigned long long t = __builtin_amdgcn_s_memtime(); (void) t; }
+        const unsigned long long t_arrive = __builtin_amdgcn_s_memtime();
+#endif
         pool_barrier(); // the phases of the round before have stored their rays
+#if defined(RT_POOL_DEBUG)
+        { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_wait += t - t_arrive; t_mark = t; }
+#endif
         const int c = fi(PF_CLS, tid);
         const bool pend = c == PC_FREE && fi(PF_QI, tid) >= 0;
         unsigned long long m[4];
@@ -653,6 +664,10 @@ __global__ __launch_bounds__(POOL_RAYS, 2) void k_traverse_pool(PassArgs a, u32 
             }
         }
 #endif
+#if defined(RT_POOL_DEBUG)
+        { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_sched += t - t_mark; t_mark = t; }
+        if (b_cls >= 0) { prof_nb[b_cls] += 1; prof_nr[b_cls] += (unsigned long long) b_cnt; } else prof_idle += 1;
+#endif
         // ---- 4. the wave's batch ---------------------------------------------------------------------------------------
         if (b_cls == PC_NODE) {
             int cur = RT_TRAVERSAL_DONE; u32 kzw = 0; float best_t = 0.0f;
@@ -673,6 +688,9 @@ __global__ __launch_bounds__(POOL_RAYS, 2) void k_traverse_pool(PassArgs a, u32 
                 const bool inner = valid && cur >= 0;
                 const int ni = __popcll(__ballot(inner));
                 if (ni == 0 || (steps > 0 && 2 * ni < b_cnt)) break;
+#if defined(RT_POOL_DEBUG)
+                prof_steps += 1;
+#endif
 #if defined(RT_POOL_DEBUG)
                 if (inner) {
                     const unsigned long long adr = (unsigned long long) nodes + ((unsigned long long) (u32) cur << 4);
@@ -813,8 +831,19 @@ __global__ __launch_bounds__(POOL_RAYS, 2) void k_traverse_pool(PassArgs a, u32 
                 fi(PF_CLS, slot) = avail > 0 ? PC_FREE : PC_IDLE; // (a segment may end inside a batch: the slot asks again)
             }
         }
+#if defined(RT_POOL_DEBUG)
+        { const unsigned long long t = __builtin_amdgcn_s_memtime(); if (b_cls >= 0) prof_batch[b_cls] += t - t_mark; t_mark = t; }
+#endif
         if (tid == 0) s_src[1] = pos + (free_taken < avail ? free_taken : (avail > 0 ? avail : 0)); // rays handed out in this round
     }
+#if defined(RT_POOL_DEBUG)
+    if (lane == 0) {
+        unsigned long long* p = a.stats->pool_prof;
+        atomicAdd(p + 0, (unsigned long long) rounds); atomicAdd(p + 1, prof_sched); atomicAdd(p + 2, prof_wait); atomicAdd(p + 3, prof_idle); atomicAdd(p + 4, prof_steps);
+        for (int k = 0; k < 4; k++) { atomicAdd(p + 5 + k, prof_batch[k]); atomicAdd(p + 9 + k, prof_nb[k]); atomicAdd(p + 13 + k, prof_nr[k]); }
+        atomicAdd(p + 17, 1ull);
+    }
+#endif
     if (COUNT) traverse_counters_flush(a, cnt);
 }
 
