@@ -98,6 +98,7 @@ struct rt_ctx {
     RayQueue q[2]; HitBuf hits; PathState ps; SlotState st[2]; GatherQueue gq; int* d_stack_spill = nullptr;
     u32* d_task_counter = nullptr; u32 persistent_slots = 0; int persistent = 0; // RT_PERSISTENT: 0 never (default), bit 0 queued launches, bit 1 primary launches
     int pool = 0; u32 cu_count = 0; // RT_POOL=2: pooled traversal for the queued launches of two-level scenes (rt_dev_pool.h), workgroups per CU; off by default (profiles/r03_ab_pool_c5.txt: right, and 2-4x slower)
+    int fuse_primary = 1; // RT_FUSE_PRIMARY: bounce 0 of the fused camera pass as one kernel in flat one-instance scenes (k_shade<.., TRACE>)
     int wave_major = 1; // RT_WAVE_MAJOR
     int xcd_bands = 1;  // RT_XCD_BANDS
     int ray_sort = 1; // RT_RAY_SORT: group the surviving rays of a bounce by direction octant (fused camera pass)
@@ -283,6 +284,11 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     // kernels run 6 waves per SIMD in wave-major order that no longer pays on any benchmark scene (k_traverse, rt_kernels.hip)
     a.persistent = c->persistent > 0 ? (u32) c->persistent : 0u;
     a.pool_groups = c->pool > 0 ? (u32) c->pool * c->cu_count : 0u;
+    a.flat_rows = c->flat_instances ? (u32) c->flat_info.depth + 2u : 0u;
+    // one kernel for bounce 0: flat trees of ONE instance (with or without the small one tested first), shallow enough for two
+    // 1,024-thread workgroups per CU (18 rows of 4 KB + the ranking's 4 KB each); the counting and capturing variants keep the two kernels
+    a.fuse_primary = (c->fuse_primary && !probe && c->flat_instances == 1u && a.flat_rows <= 18u && c->persistent <= 0 &&
+                      !(c->flags & (RT_FLAG_COUNT_TRAVERSAL))) ? 1u : 0u;
     a.dbg_blas_lo = ~0ull; a.dbg_blas_hi = 0ull;
     for (const Blas& b : c->blas) {
         const u32 nn = b.n_tris > 1 ? b.n_tris - 1 : 1;
@@ -379,6 +385,22 @@ int timed_traverse(rt_ctx* c, const PassArgs& a, u32 inq, bool primary, u32 samp
     return rc;
 }
 
+// bounce 0 as one kernel (PassArgs::fuse_primary): counted and timed as the frame's primary traversal launch (its duration
+// now includes the bounce-0 shade)
+int timed_primary_fused(rt_ctx* c, const PassArgs& a, u32 sample_index) {
+    bool timing = timing_now(c);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) {
+        RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
+        RT_HIP(hipEventRecord(e0, c->stream));
+        c->traverse_launches_timed++; c->primary_launches_timed++;
+    }
+    int rc = launch_shade(c->stream, a, 0u, 0u, sample_index, true, true);
+    if (timing) { RT_HIP(hipEventRecord(e1, c->stream)); c->timed_primary.emplace_back(e0, e1); }
+    c->traverse_launches++; c->primary_launches++; c->primary_rays += local_pixel_count(a);
+    return rc;
+}
+
 int timed_gather(rt_ctx* c, const PassArgs& a) {
     bool timing = timing_now(c);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -444,8 +466,11 @@ int run_pass(rt_ctx* c, bool probe) {
         if (probe) { rc = launch_probe_raygen(c->stream, a, s); if (rc) return rc; }
         for (u32 b = 0; b <= c->g.bounces_per_sample; b++) {
             bool primary = !probe && b == 0;
-            rc = timed_traverse(c, a, b & 1u, primary, s); if (rc) return rc;
-            rc = launch_shade(c->stream, a, b & 1u, b, s, primary, fused); if (rc) return rc;
+            if (primary && fused && a.fuse_primary) { rc = timed_primary_fused(c, a, s); if (rc) return rc; } // walk + shade in one kernel
+            else {
+                rc = timed_traverse(c, a, b & 1u, primary, s); if (rc) return rc;
+                rc = launch_shade(c->stream, a, b & 1u, b, s, primary, fused); if (rc) return rc;
+            }
             if (gather && (int) b <= c->g.translucent_emission_bounces) { rc = timed_gather(c, a); if (rc) return rc; }
         }
     }
@@ -667,6 +692,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_SAH_TRI")) c->sah_tri = (float) atof(v);
     if (const char* v = getenv("RT_RAY_SORT")) c->ray_sort = atoi(v);
     if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
+    if (const char* v = getenv("RT_FUSE_PRIMARY")) c->fuse_primary = atoi(v);
     if (const char* v = getenv("RT_POOL")) c->pool = atoi(v);
     if (const char* v = getenv("RT_GATHER_L1")) c->gather_l1 = atoi(v);
     if (const char* v = getenv("RT_XCD_BANDS")) c->xcd_bands = atoi(v);

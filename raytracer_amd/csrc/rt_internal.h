@@ -145,6 +145,7 @@ struct PassArgs {
     u32 persistent;              // bit 0: queued (secondary / probe) launches persistent, bit 1: primary launches too
     u32 pool_groups;             // > 0: queued launches of two-level scenes run the pooled traversal (rt_dev_pool.h) on this many persistent workgroups (RT_POOL)
     unsigned long long dbg_blas_lo, dbg_blas_hi; u32 dbg_tlas_bytes; // RT_POOL_DEBUG builds: address range of all bottom-level trees, size of the top-level node array
+    u32 fuse_primary, flat_rows; // bounce 0 of the fused camera pass walks and shades in one kernel (k_shade<.., TRACE>); stack rows its walk needs (flat tree depth + 2)
     u32 lazy_render_target;      // the resolve leaves the render target alone (rt_api.hip derives it from the accumulator when it is read)
     u32 defer_resolve;           // fused camera pass: finished paths leave their pixel's sample sum in ps.sum_* for k_frame_resolve
     u32 stack_in_lds;            // the trees are shallow enough for the LDS rows of the traversal stack alone (LaneStack<false>)

@@ -851,8 +851,16 @@ __global__ __launch_bounds__(POOL_RAYS, 2) void k_traverse_pool(PassArgs a, u32 
 // PRIMARY: bounce 0 of the camera pass (thread t shades pixel thread_pixel(t); the path state starts here).
 // FUSED: a path that ends here also finishes its pixel (sample sum, accumulate, tone-map) -- no resolve kernel, and no
 // radiance / alpha / sum traffic for finished paths.  Not usable while the gather kernel may add emission afterwards.
-template <bool PRIMARY, bool FUSED>
+// TRACE > 0 (with PRIMARY and FUSED; flat scenes, TRACE = the FLAT kind of k_traverse: 1 one instance, 3 one instance and a
+// small one tested first): bounce 0 in ONE kernel -- the thread derives its primary ray once, walks it here (trace_flat, the
+// stack in its wave's rows of dynamic LDS) and shades what it found: no second derivation of the ray (~110 vector instructions
+// per lane of the separate bounce-0 shade), no hit record through memory, one launch less per sample.  The stack rows and the
+// staging arrays of the compaction share the dynamic LDS (the walk is over, for all 16 waves, before the first staging store:
+// the ranking in between starts with a barrier).
+template <bool PRIMARY, bool FUSED, int TRACE = 0>
 __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounce, u32 sample_index) { // 8 waves per SIMD = two workgroups per CU: at most 64 VGPRs
+    static_assert(TRACE == 0 || (PRIMARY && FUSED && (TRACE == 1 || TRACE == 3)), "the fused bounce-0 kernel walks a flat tree of one instance");
+    extern __shared__ int s_dyn[]; // TRACE: max(a.flat_rows, 14) x 1024 words
     __shared__ u32 s_wave[SEG / 64];
     const u32 qi = blockIdx.x * SEG + threadIdx.x;
     bool active, cont = false, gather = false, zero_sample = false, record = false;
@@ -904,12 +912,23 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
     }
     if (active) {
         HitOut h;
+        if (TRACE > 0) { // the walk of k_traverse<.., PRIMARY, .., FLAT = TRACE>, here
+            LaneStack<false> st; st.lds = (RT_LDS int*) &s_dyn[(threadIdx.x >> 6) * a.flat_rows * TRAVERSE_WAVE + (threadIdx.x & 63u)];
+            st.spill = nullptr; st.spill_stride = 0; st.sp = 0;
+            TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
+            trace_flat<1, LaneStack<false>, false, false, true, TRACE == 3>(a.scene, o, d, a.tmin, a.tmax, st, h, cnt);
+            if (h.inst < 0) { h.t = inf_f32(); h.u = 0.0f; h.v = 0.0f; h.tri = -1; }
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the last stack store has landed before the rows are reused (pool_barrier: hipcc can drop the barrier's own wait)
+#endif
+        } else {
         const float4 rec = ((const float4*) a.hits.t)[qi]; // (t, u, v, id) as k_traverse wrote it
         h.inst = __float_as_int(rec.w); h.t = inf_f32(); h.u = 0.0f; h.v = 0.0f; h.tri = -1;
         if (h.inst >= 0) {
             h.t = rec.x; h.u = rec.y; h.v = rec.z;
             if (a.scene.flat_instances) { h.tri = h.inst & 0x3fffffff; h.inst = h.inst >> 30; } // uniform
             else h.tri = a.hits.tri[qi];
+        }
         }
         h.prim_global = 0;
         float payload_t = a.probe ? inf_f32() : (float) bounce; // raytracing.hlsl:102-107
@@ -1025,7 +1044,8 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         // a.ray_sort is set: rays of one origin neighbourhood (the tile) and one octant walk the BVH alike, which cuts
         // the trips a wave makes through the traversal loop by ~20 % (C2: SIMD efficiency of node steps 0.35 -> 0.44).
         // Ray and path state go through LDS so that the queue is written in slot order, coalesced, whatever the ranking.
-        __shared__ float s_stage[14][SEG];
+        __shared__ float s_stage_own[TRACE > 0 ? 1 : 14][SEG];
+        float (*const s_stage)[SEG] = TRACE > 0 ? (float (*)[SEG]) s_dyn : s_stage_own; // TRACE: the stack rows, no longer in use
         const u32 ls = rank_sorted();
         const bool rad_zero = __syncthreads_or(cont && (as_u32(rad.x) | as_u32(rad.y) | as_u32(rad.z)) != 0u) == 0; // uniform
         if (threadIdx.x == 0) a.seg_count[inq ^ 1u][blockIdx.x] = total | (rad_zero ? SEG_RAD_ZERO : 0u);
@@ -1600,7 +1620,17 @@ int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32
     size_t n = pass_paths(a);
     if (!n) return RT_OK;
     dim3 grid(a.n_segments), block(SEG);
-    if (primary && fused) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, s, a, in_queue, bounce, sample_index);
+    if (primary && fused && a.fuse_primary) { // bounce 0 in one kernel: walk and shade (no launch_traverse before it)
+        const size_t lds = (size_t) (a.flat_rows > 14u ? a.flat_rows : 14u) * SEG * sizeof(int);
+        if (a.scene.flat_inl_inst >= 0) {
+            RT_HIP(hipFuncSetAttribute((const void*) k_shade<true, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            hipLaunchKernelGGL((k_shade<true, true, 3>), grid, block, lds, s, a, in_queue, bounce, sample_index);
+        } else {
+            RT_HIP(hipFuncSetAttribute((const void*) k_shade<true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            hipLaunchKernelGGL((k_shade<true, true, 1>), grid, block, lds, s, a, in_queue, bounce, sample_index);
+        }
+    }
+    else if (primary && fused) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, s, a, in_queue, bounce, sample_index);
     else if (primary) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, s, a, in_queue, bounce, sample_index);
     else if (fused) hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, s, a, in_queue, bounce, sample_index);
     else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, s, a, in_queue, bounce, sample_index);
