@@ -98,6 +98,7 @@ struct rt_ctx {
     RayQueue q[2]; HitBuf hits; PathState ps; SlotState st[2]; GatherQueue gq; int* d_stack_spill = nullptr;
     u32* d_task_counter = nullptr; u32 persistent_slots = 0; int persistent = 0; // RT_PERSISTENT: 0 never (default), bit 0 queued launches, bit 1 primary launches
     int pool = 0; u32 cu_count = 0; // RT_POOL=2: pooled traversal for the queued launches of two-level scenes (rt_dev_pool.h), workgroups per CU; off by default (profiles/r03_ab_pool_c5.txt: right, and 2-4x slower)
+    int fuse_tail = 1; // RT_FUSE_TAIL: the last bounce's traversal kernel of the fused camera pass shades its hits itself
     int fuse_primary = 1; // RT_FUSE_PRIMARY: bounce 0 of the fused camera pass as one kernel in flat one-instance scenes (k_shade<.., TRACE>)
     int wave_major = 1; // RT_WAVE_MAJOR
     int xcd_bands = 1;  // RT_XCD_BANDS
@@ -370,7 +371,7 @@ bool timing_now(const rt_ctx* c) {
     return (c->flags & RT_FLAG_TIME_KERNELS) != 0 && (!(c->flags & RT_FLAG_TIME_SAMPLED) || c->dispatch_index % 8u == 0u);
 }
 
-int timed_traverse(rt_ctx* c, const PassArgs& a, u32 inq, bool primary, u32 sample_index) {
+int timed_traverse(rt_ctx* c, const PassArgs& a, u32 inq, bool primary, u32 sample_index, bool tail_shade = false) {
     bool timing = timing_now(c);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) {
@@ -378,7 +379,7 @@ int timed_traverse(rt_ctx* c, const PassArgs& a, u32 inq, bool primary, u32 samp
         RT_HIP(hipEventRecord(e0, c->stream));
         c->traverse_launches_timed++;
     }
-    int rc = launch_traverse(c->stream, a, inq, (c->flags & RT_FLAG_COUNT_TRAVERSAL) != 0, primary, sample_index);
+    int rc = launch_traverse(c->stream, a, inq, (c->flags & RT_FLAG_COUNT_TRAVERSAL) != 0, primary, sample_index, tail_shade);
     if (timing) { RT_HIP(hipEventRecord(e1, c->stream)); (primary ? c->timed_primary : c->timed).emplace_back(e0, e1); if (primary) c->primary_launches_timed++; }
     c->traverse_launches++;
     if (primary) { c->primary_launches++; c->primary_rays += local_pixel_count(a); } // bounce-0 rays are not queued, so the device does not count them
@@ -468,8 +469,11 @@ int run_pass(rt_ctx* c, bool probe) {
             bool primary = !probe && b == 0;
             if (primary && fused && a.fuse_primary) { rc = timed_primary_fused(c, a, s); if (rc) return rc; } // walk + shade in one kernel
             else {
-                rc = timed_traverse(c, a, b & 1u, primary, s); if (rc) return rc;
-                rc = launch_shade(c->stream, a, b & 1u, b, s, primary, fused); if (rc) return rc;
+                // the last bounce of the fused pass ends every path: its traversal kernel shades the hits itself (k_traverse, `tail`)
+                const bool tail_shade = c->fuse_tail && fused && !primary && !capture && b == c->g.bounces_per_sample && a.pool_groups == 0u && c->flat_instances != 2u &&
+                                        !(c->flags & RT_FLAG_COUNT_TRAVERSAL) && c->persistent <= 0;
+                rc = timed_traverse(c, a, b & 1u, primary, s, tail_shade); if (rc) return rc;
+                if (!tail_shade) { rc = launch_shade(c->stream, a, b & 1u, b, s, primary, fused); if (rc) return rc; }
             }
             if (gather && (int) b <= c->g.translucent_emission_bounces) { rc = timed_gather(c, a); if (rc) return rc; }
         }
@@ -693,6 +697,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_RAY_SORT")) c->ray_sort = atoi(v);
     if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
     if (const char* v = getenv("RT_FUSE_PRIMARY")) c->fuse_primary = atoi(v);
+    if (const char* v = getenv("RT_FUSE_TAIL")) c->fuse_tail = atoi(v);
     if (const char* v = getenv("RT_POOL")) c->pool = atoi(v);
     if (const char* v = getenv("RT_GATHER_L1")) c->gather_l1 = atoi(v);
     if (const char* v = getenv("RT_XCD_BANDS")) c->xcd_bands = atoi(v);

@@ -195,7 +195,8 @@ struct PassArgs {
 
 int launch_probe_raygen(hipStream_t s, const PassArgs& a, u32 sample_index);
 // primary: bounce 0 of the camera pass (rays derived from pixels; in_queue unused)
-int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, bool primary, u32 sample_index);
+// tail_shade (queued launches, last bounce of the fused camera pass): the kernel shades its hits itself, no launch_shade follows
+int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, bool primary, u32 sample_index, bool tail_shade = false);
 // fused: finished camera paths resolve their pixel in the shade kernel (no launch_camera_resolve afterwards)
 int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index, bool primary, bool fused);
 int launch_gather(hipStream_t s, const PassArgs& a);

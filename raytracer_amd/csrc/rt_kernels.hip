@@ -349,6 +349,24 @@ __global__ __launch_bounds__(BT) void k_probe_resolve(PassArgs a) {
     a.sp_write[p] = sp;
 }
 
+// A camera path of the fused pass has ended at a bounce > 0 with radiance `rad`: its sample goes into the pixel exactly as
+// k_shade<false, true> folds it (the same additions in the same order; pipelined frames: a record for k_frame_resolve).
+RT_DEV void fused_sample_done(const PassArgs& a, u32 path, f3 rad, u32 sample_index, u32 rng) {
+    float smp[4] = { rad.x, rad.y, rad.z, 1.0f }, tot[4];
+    float* const sum[4] = { a.ps.sum_x, a.ps.sum_y, a.ps.sum_z, a.ps.sum_a };
+    for (int k = 0; k < 4; k++) tot[k] = (sample_index == 0 ? 0.0f : sum[k][path]) + smp[k];
+    if (sample_index + 1u < a.g.samples_per_pixel) {
+        a.ps.rng[path] = rng; // the next sample of this pixel continues the stream (raytracing.hlsl:130,141)
+        for (int k = 0; k < 4; k++) sum[k][path] = tot[k];
+    } else if ((as_u32(rad.x) | as_u32(rad.y) | as_u32(rad.z)) == 0u && frame_masks_in_use(a)) { /* ended dark: no record */ }
+    else if (a.defer_resolve) { // k_frame_resolve adds it in
+        if (frame_masks_in_use(a)) atomicOr(frame_record_mask(a) + (path >> 6), 1ull << (path & 63u));
+        if (a.g.samples_per_pixel == 1u) ((float4*) a.ps.sum_x)[path] = make_float4(tot[0], tot[1], tot[2], tot[3]);
+        else for (int k = 0; k < 4; k++) sum[k][path] = tot[k];
+    }
+    else resolve_pixel(a, path, tot);
+}
+
 // ---- TraceRay ---------------------------------------------------------------------------------------------------
 RT_DEV void traverse_counters_flush(const PassArgs& a, const TraverseCounters& cnt) {
     u32 sn = wave_sum(cnt.nodes), stt = wave_sum(cnt.tris), si = wave_sum(cnt.insts);
@@ -383,7 +401,10 @@ static constexpr u32 TASK_PARTS = 64, TASK_STRIDE = 32; // counters 128 bytes ap
 // FLAT = K > 0: the scene has K <= RT_FLAT_MAX_INSTANCES instances and one tree over all their triangles (trace_flat,
 // rt_dev_scene.h); the stack then has all 26 LDS rows to itself (no side store; the host checks the depth).
 template <bool COUNT, int WAVES_PER_SIMD, bool PRIMARY, bool PERSISTENT, bool SPILL, int FLAT = 0>
-__global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq, u32 sample_index, u32 n_tasks) {
+__global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(PassArgs a, u32 inq, u32 sample_index, u32 n_tasks, u32 tail) {
+    // tail (queued launches of the fused camera pass, last bounce): every path ends with this ray and only the emission of what it
+    // hits still counts, so the wave shades its rays itself -- what k_shade<false, true> does at that bounce (no compaction there:
+    // nothing the workgroup has to do together) -- instead of handing 16-byte hit records to one more kernel
     // DEEP: two-level trees too deep for the 17 stack rows of the 6-wave kernels but not for 33 (sentinel + top-level depth +
     // marker + bottom-level depth + the row above the top: the 52,743-instance field needs exactly 33): 5 waves per SIMD
     // by registers, 19 per CU by their 8.25 KB of LDS, all of it stack, the side store in registers (LaneStack SIDE_REGS)
@@ -431,6 +452,7 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
         u32 next = 0;
         if (PERSISTENT && threadIdx.x == 0) next = atomicAdd(a.task_counter + part * TASK_STRIDE, 1u); // asked for early: back before the rays are
         u32 qi = task * TRAVERSE_WAVE + threadIdx.x;
+        u32 seg_fill = 0;
         bool active;
         f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
         if (PRIMARY) {
@@ -451,7 +473,8 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
                 sum = wave_sum(sum);
                 if (threadIdx.x == 0) atomicAdd(a.probe ? &a.stats->rays_probe : &a.stats->rays_camera, (unsigned long long) sum);
             }
-            active = idx < (a.seg_count[inq][seg] & SEG_FILL_MASK);
+            seg_fill = a.seg_count[inq][seg];
+            active = idx < (seg_fill & SEG_FILL_MASK);
             if (active) {
                 const RayQueue& q = a.q[inq];
                 o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
@@ -477,11 +500,25 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
             // RT_FLAT_MAX_INSTANCES is 2 and their triangles number < 2^20; otherwise id = instance and the triangle goes to its
             // own array.  A miss is id = -1; the other words are then not read.
             static_assert(RT_FLAT_MAX_INSTANCES <= 2 && RT_FLAT_MAX_TRIS <= (1u << 30), "hit id packing");
+            if (!PRIMARY && !COUNT && FLAT != 2 && tail) { // uniform (not compiled into the two-instance flat kernels: they sit at their 72-VGPR limit, and their scenes shade in k_shade)
+                const u32 path = a.q[inq].path[qi];
+                const SlotState& ss = a.st[inq];
+                const f3 thr_prev = mk3(ss.thr_x[qi], ss.thr_y[qi], ss.thr_z[qi]);
+                f3 rad = mk3(0.0f, 0.0f, 0.0f);
+                if (!(seg_fill & SEG_RAD_ZERO)) rad = mk3(ss.rad_x[qi], ss.rad_y[qi], ss.rad_z[qi]);
+                u32 rng = sample_index + 1u < a.g.samples_per_pixel ? ss.rng[qi] : 0u; // dead unless the pixel has another sample to come
+                if (best.inst < 0) { best.t = inf_f32(); best.u = 0.0f; best.v = 0.0f; best.tri = -1; }
+                ShadeOut r;
+                shade_ray(a.shade, a.g, a.fudge, o, d, best, (float) a.g.bounces_per_sample, rng, r, true);
+                rad = rad + r.emission * thr_prev;            // raytracing.hlsl:113
+                fused_sample_done(a, path, rad, sample_index, rng);
+            } else {
             const bool packed = FLAT > 0 || a.scene.flat_instances != 0u; // uniform
             int id = best.inst;
             if (packed) id = best.inst < 0 ? -1 : (best.inst << 30) | best.tri;
             ((float4*) a.hits.t)[qi] = make_float4(best.t, best.u, best.v, __int_as_float(id));
             if (!packed && best.inst >= 0) a.hits.tri[qi] = best.tri;
+            }
         }
         if (!PERSISTENT) break;
         task = next * TASK_PARTS + part < n_tasks ? next * TASK_PARTS + part : n_tasks;
@@ -1542,9 +1579,10 @@ int launch_probe_raygen(hipStream_t s, const PassArgs& a, u32 sample_index) {
     return RT_OK;
 }
 static size_t pass_paths(const PassArgs& a) { return (size_t) a.n_segments * SEG; }
-int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, bool primary, u32 sample_index) {
+int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, bool primary, u32 sample_index, bool tail_shade) {
     size_t n = pass_paths(a);
     if (!n) return RT_OK;
+    const u32 tail = (tail_shade && !primary && !count_traversal && a.scene.flat_instances != 2u) ? 1u : 0u;
     dim3 grid = blocks(n, TRAVERSE_WAVE), block(TRAVERSE_WAVE);
     const u32 n_tasks = grid.x;
     // 6 waves per SIMD = 80 VGPRs = what the LDS stacks allow as well (6.5 KB per wave); the persistent variant keeps 5 (it needs 96)
@@ -1571,47 +1609,47 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
         else hipLaunchKernelGGL((k_traverse_pool<false, 17>), pgrid, pblock, lds, s, a, in_queue);
     } else if (persistent) {
         dim3 pgrid(a.persistent_slots);
-        if (primary) hipLaunchKernelGGL((k_traverse<false, 5, true, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
-        else hipLaunchKernelGGL((k_traverse<false, 5, false, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        if (primary) hipLaunchKernelGGL((k_traverse<false, 5, true, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+        else hipLaunchKernelGGL((k_traverse<false, 5, false, true, true>), pgrid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
     } else if (a.scene.flat_instances == 1u && a.scene.flat_inl_inst >= 0) {
         // one tree over the big instance of two, the small one tested first
         if (primary) {
-            if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-            else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, true, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-            else hipLaunchKernelGGL((k_traverse<false, 6, true, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+            if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+            else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, true, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+            else hipLaunchKernelGGL((k_traverse<false, 6, true, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
         } else {
-            if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-            else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, false, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-            else hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+            if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+            else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, false, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+            else hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 3>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
         }
     } else if (a.scene.flat_instances == 1u || a.scene.flat_instances == 2u) {
         // one tree over the triangles of all (one or two) instances; count_traversal: the same walk with the counters on
         const bool two = a.scene.flat_instances == 2u;
         if (primary) {
-            if (count_traversal) { if (two) hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-                                   else hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks); }
-            else if (two && a.flat_waves7) hipLaunchKernelGGL((k_traverse<false, 7, true, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-            else if (two) hipLaunchKernelGGL((k_traverse<false, 6, true, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-            else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-            else hipLaunchKernelGGL((k_traverse<false, 6, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+            if (count_traversal) { if (two) hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+                                   else hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail); }
+            else if (two && a.flat_waves7) hipLaunchKernelGGL((k_traverse<false, 7, true, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+            else if (two) hipLaunchKernelGGL((k_traverse<false, 6, true, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+            else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+            else hipLaunchKernelGGL((k_traverse<false, 6, true, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
         } else {
-            if (count_traversal) { if (two) hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-                                   else hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks); }
-            else if (two && a.flat_waves7) hipLaunchKernelGGL((k_traverse<false, 7, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-            else if (two) hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-            else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-            else hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+            if (count_traversal) { if (two) hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+                                   else hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail); }
+            else if (two && a.flat_waves7) hipLaunchKernelGGL((k_traverse<false, 7, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+            else if (two) hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+            else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+            else hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
         }
     } else if (primary) {
-        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-        else if (a.stack_in_lds == 2u) hipLaunchKernelGGL((k_traverse<false, 5, true, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-        else if (a.stack_in_lds) hipLaunchKernelGGL((k_traverse<false, 6, true, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-        else hipLaunchKernelGGL((k_traverse<false, 6, true, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+        else if (a.stack_in_lds == 2u) hipLaunchKernelGGL((k_traverse<false, 5, true, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+        else if (a.stack_in_lds) hipLaunchKernelGGL((k_traverse<false, 6, true, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+        else hipLaunchKernelGGL((k_traverse<false, 6, true, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
     } else {
-        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, false, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-        else if (a.stack_in_lds == 2u) hipLaunchKernelGGL((k_traverse<false, 5, false, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-        else if (a.stack_in_lds) hipLaunchKernelGGL((k_traverse<false, 6, false, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
-        else hipLaunchKernelGGL((k_traverse<false, 6, false, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks);
+        if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, false, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+        else if (a.stack_in_lds == 2u) hipLaunchKernelGGL((k_traverse<false, 5, false, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+        else if (a.stack_in_lds) hipLaunchKernelGGL((k_traverse<false, 6, false, false, false>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+        else hipLaunchKernelGGL((k_traverse<false, 6, false, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
     }
     RT_HIP(hipGetLastError());
     return RT_OK;
