@@ -1,21 +1,28 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/final_measure.sh <tag>
-# bench lines of all workloads + rocprofv3 kernel stats of the default command -> gpurun_out/<tag>_*
+# usage (on the GPU box, from the repo root): bash tools/final_measure.sh <stage> <tag>
+#   pmc    counter passes of every BASELINE configuration -> gpurun_out/pmc_<key>.json (merge: tools/pmc_merge.py, then commit)
+#   bench  the bench lines (with the CPU leg and the roofline from the merged profiles/pmc_traffic.json) -> gpurun_out/<tag>_<config>.json
+#   prof   rocprofv3 --kernel-trace --stats of each configuration's bench command -> gpurun_out/<tag>_<config>_kernel_stats.csv,
+#          traversal counters, BVH build throughput
 set -u
-tag=$1
+stage=$1; tag=${2:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-timeout -k 10 300 python3 bench.py > gpurun_out/${tag}_c2.json 2> gpurun_out/${tag}_c2.err || { echo "c2 failed"; tail -5 gpurun_out/${tag}_c2.err; exit 1; }
-echo "c2 done"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof_c2 -o c2 --output-format csv -- python3 bench.py --no-cpu --no-alone > gpurun_out/${tag}_prof_c2.log 2>&1 || { echo "rocprof c2 failed"; exit 1; }
-echo "rocprof c2 done"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof_c3 -o c3 --output-format csv -- python3 bench.py --no-cpu --no-alone --workload c3 --spp 4 > gpurun_out/${tag}_prof_c3.log 2>&1 || { echo "rocprof c3 failed"; exit 1; }
-echo "rocprof c3 done"
-for w in c3 c3t c4; do
-  timeout -k 10 300 python3 bench.py --no-cpu --workload $w > gpurun_out/${tag}_$w.json 2> gpurun_out/${tag}_$w.err || { echo "$w failed"; tail -5 gpurun_out/${tag}_$w.err; exit 1; }
-  echo "$w done"
-done
-timeout -k 10 300 python3 bench.py --no-cpu --workload c5 --width 3840 --height 2160 > gpurun_out/${tag}_c5_4k.json 2> gpurun_out/${tag}_c5.err || { echo "c5 failed"; exit 1; }
-echo "c5 4k done"
-timeout -k 10 300 python3 bench.py --no-cpu --workload c5 > gpurun_out/${tag}_c5_1080p.json 2>> gpurun_out/${tag}_c5.err || { echo "c5 failed"; exit 1; }
-timeout -k 10 200 python3 tools/build_bench.py > gpurun_out/${tag}_build.txt 2>&1 || { echo "build bench failed"; exit 1; }
-echo "all done"
+case $stage in
+pmc)
+  bash tools/pmc_passes.sh c2 --steps 40 --warmup 5 && bash tools/pmc_passes.sh c3 --workload c3 --steps 3 --warmup 1 &&
+  bash tools/pmc_passes.sh c4 --workload c4 --steps 3 --warmup 1 && bash tools/pmc_passes.sh c5 --workload c5 --steps 16 --warmup 2 &&
+  bash tools/pmc_passes.sh c5_3840x2160 --workload c5 --width 3840 --height 2160 --steps 16 --warmup 2 || exit 1 ;;
+bench)
+  run() { name=$1; shift; timeout -k 10 400 python3 bench.py "$@" > gpurun_out/${tag}_$name.json 2> gpurun_out/${tag}_$name.err || { echo "$name failed"; tail -5 gpurun_out/${tag}_$name.err; exit 1; }; echo "$name done"; }
+  run c2 ; run c2_driver --steps 20 --warmup 5 --no-cpu ; run c3 --workload c3 --steps 10 ; run c4 --workload c4 --steps 20
+  run c5_4k --workload c5 --width 3840 --height 2160 --steps 60 ; run c5_1080p --workload c5 --steps 100 ; run c3t --workload c3t --no-cpu ;;
+prof)
+  prof() { name=$1; shift; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof_$name -o $name --output-format csv -- python3 bench.py --no-cpu --no-alone "$@" > gpurun_out/${tag}_prof_$name.log 2>&1 || { echo "rocprof $name failed"; tail -5 gpurun_out/${tag}_prof_$name.log; exit 1; }
+    cp gpurun_out/${tag}_prof_$name/*/${name}_kernel_stats.csv gpurun_out/${tag}_${name}_kernel_stats.csv 2>/dev/null || cp gpurun_out/${tag}_prof_$name/${name}_kernel_stats.csv gpurun_out/${tag}_${name}_kernel_stats.csv || exit 1
+    rm -rf gpurun_out/${tag}_prof_$name; echo "rocprof $name done"; }
+  prof c2 ; prof c3 --workload c3 --steps 4 ; prof c4 --workload c4 --steps 6 ; prof c5_4k --workload c5 --width 3840 --height 2160 --steps 24
+  timeout -k 10 200 python3 tools/count_traversal.py c2 c3 c4 c5 c5_4k > gpurun_out/${tag}_traversal_counters.txt 2>&1 || { echo "counters failed"; exit 1; }
+  timeout -k 10 200 python3 tools/build_bench.py > gpurun_out/${tag}_bvh_build_throughput.txt 2>&1 || { echo "build bench failed"; exit 1; } ;;
+*) echo "unknown stage $stage"; exit 2 ;;
+esac
+echo "stage $stage done"
