@@ -372,6 +372,23 @@ def main():
                 pmc_note = "no PMC passes committed for %r" % key
         cyc_best, cyc_mix = valu_issue_cycles()
         traffic = insts = achieved = peak = frac = traffic_frac = mix_frac = valu_busy = None
+        # Flat one-instance scenes walk AND shade bounce 0 in one kernel (k_shade<true, true, N>: RtStats.fused_bounce0): the launches
+        # of k_traverse are then the queued ones alone, and the roofline's launch time is theirs; the bounce-0 kernel gets a line
+        # of its own (`bounce0_kernel`)
+        fused0 = bool(stats.get("fused_bounce0"))
+        bounce0 = None
+        if fused0:
+            mean_launch_ms = sec_ms / sec_timed if sec_timed > 0 else 0.0
+            rays_per_launch = sec_rays / max(sec_launches, 1)
+            model_gbs = (b_trav * rays_per_launch) / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
+            k0 = [k for k in (pmc_all or {}) if k.startswith("k_shade<true, true, ") and not k.endswith(", 0>")]
+            if k0 and stats["primary_launches_timed"] > 0 and cyc_best:
+                k0 = max(k0, key=lambda k: pmc_all[k]["launches_sampled"])
+                ms0 = stats["primary_ms"] / stats["primary_launches_timed"]
+                bounce0 = {"kernel": k0, "valu_insts_per_launch": pmc_all[k0]["SQ_INSTS_VALU"], "mean_launch_ms": ms0,
+                           "achieved": pmc_all[k0]["SQ_INSTS_VALU"] / (ms0 * 1e-3) / 1e9, "unit": "Ginst/s",
+                           "frac": pmc_all[k0]["SQ_INSTS_VALU"] / (ms0 * 1e-3) / 1e9 / (SIMDS * CLOCK_GHZ / cyc_best),
+                           "traffic": pmc_all[k0].get("traffic_bytes_per_launch")}
         if pmc is not None:
             traffic = pmc.get("traffic_bytes_per_launch")
             insts = pmc.get("SQ_INSTS_VALU")
@@ -412,10 +429,9 @@ def main():
         if pmc_all is not None and args.workload == "c2" and cyc_mix:
             try:
                 ks = pmc_all
-                def timed_traverse(primary):  # the instantiation the timed frames ran (not the counting one): the most launches
-                    cand = [k for k in ks if k.startswith("k_traverse<false, ") and k.split(", ")[2] == primary]
-                    return max(cand, key=lambda k: ks[k]["launches_sampled"])
-                per_frame = [timed_traverse("true"), timed_traverse("false"), "k_shade<true, true>", "k_shade<false, true>", "k_frame_resolve"]
+                # the kernels every frame runs once: the instantiations (and k_frame_resolve) sampled about as often as the most sampled one
+                most = max(v["launches_sampled"] for v in ks.values())
+                per_frame = [k for k, v in ks.items() if ("<" in k or k == "k_frame_resolve") and v["launches_sampled"] >= 0.9 * most and v.get("SQ_INSTS_VALU")]
                 frame_insts = sum(ks[k]["SQ_INSTS_VALU"] for k in per_frame)
                 frame_issue_frac = frame_insts * cyc_mix / (dt_max / args.steps * SIMDS * CLOCK_GHZ * 1e9)
             except (KeyError, ValueError):
@@ -449,9 +465,11 @@ def main():
                          # (selects, v_fma_mix, min / max run at half the fma rate on gfx950): how full the issue slots are
                          "frac_at_mix_cost": mix_frac, "valu_busy_pmc": valu_busy,
                          "frame_valu_insts": frame_insts, "frame_issue_frac_at_mix_cost": frame_issue_frac,
+                         "launches_of": "queued k_traverse launches (bounce 0 runs in k_shade<true, true, N>: bounce0_kernel)" if fused0 else "all k_traverse launches",
+                         "bounce0_kernel": bounce0,
                          "mean_launch_ms": mean_launch_ms, "rays_per_launch": rays_per_launch,
                          "traverse_Mrays_s": rays_timed / (stats["traverse_ms"] * 1e-3) / 1e6 if stats["traverse_ms"] > 0 else None,
-                         "launches_timed": stats["traverse_launches_timed"], "launches": stats["traverse_launches"],
+                         "launches_timed": sec_timed if fused0 else stats["traverse_launches_timed"], "launches": sec_launches if fused0 else stats["traverse_launches"],
                          # SURVEY 8(d)'s algorithmic byte model (64-byte nodes, every byte priced as if it came from HBM)
                          "model": {"bytes_per_ray_traverse": b_trav, "bytes_per_ray_pipeline": b_ray,
                                    "algorithmic_bytes_per_launch": b_trav * rays_per_launch, "GBs": model_gbs,

@@ -151,6 +151,9 @@ typedef struct RtStats {
                                       /* kernels: traversal runs without the global overflow path; 0 = with it                     */
     uint32_t flat_depth;              /* > 0: the scene (<= 2 instances) is traversed in ONE tree over all instanced triangles, of   */
                                       /* this many inner-node levels, instead of the two levels; 0 = two levels */
+    uint32_t fused_bounce0;           /* 1 = camera dispatches without the BSSRDF gather walk AND shade bounce 0 in one kernel (flat one-instance */
+                                      /* scenes): that launch is counted in primary_launches / primary_ms, and no separate bounce-0 shade runs   */
+    uint32_t fused_tail;              /* 1 = their last bounce is shaded inside its traversal kernel                                             */
 } RtStats;
 
 /* rt_set_flags bits */

@@ -98,6 +98,10 @@ struct rt_ctx {
     RayQueue q[2]; HitBuf hits; PathState ps; SlotState st[2]; GatherQueue gq; int* d_stack_spill = nullptr;
     u32* d_task_counter = nullptr; u32 persistent_slots = 0; int persistent = 0; // RT_PERSISTENT: 0 never (default), bit 0 queued launches, bit 1 primary launches
     int pool = 0; u32 cu_count = 0; // RT_POOL=2: pooled traversal for the queued launches of two-level scenes (rt_dev_pool.h), workgroups per CU; off by default (profiles/r03_ab_pool_c5.txt: right, and 2-4x slower)
+    // the BSSRDF gather of a bounce on a side stream, beside the next bounce's traversal (run_pass): one side stream and two
+    // events per lane, made with the lane (ensure_gather_side); RT_GATHER_SIDE=1 -- measured, not kept (profiles/r03_ab_gather_side.txt): default in stream order
+    int gather_side = 0; hipStream_t gather_stream[2] = { nullptr, nullptr }; hipEvent_t gather_ev[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };
+    int cur_lane = 0; bool gather_pending = false;
     int fuse_tail = 1; // RT_FUSE_TAIL: the last bounce's traversal kernel of the fused camera pass shades its hits itself
     int fuse_primary = 1; // RT_FUSE_PRIMARY: bounce 0 of the fused camera pass as one kernel in flat one-instance scenes (k_shade<.., TRACE>)
     int wave_major = 1; // RT_WAVE_MAJOR
@@ -402,18 +406,47 @@ int timed_primary_fused(rt_ctx* c, const PassArgs& a, u32 sample_index) {
     return rc;
 }
 
-int timed_gather(rt_ctx* c, const PassArgs& a) {
+int timed_gather(rt_ctx* c, const PassArgs& a, hipStream_t stream) {
     bool timing = timing_now(c);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) {
         RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
-        RT_HIP(hipEventRecord(e0, c->stream));
+        RT_HIP(hipEventRecord(e0, stream));
         c->gather_launches_timed++;
     }
-    int rc = launch_gather(c->stream, a);
-    if (timing) { RT_HIP(hipEventRecord(e1, c->stream)); c->timed_gather.emplace_back(e0, e1); }
+    int rc = launch_gather(stream, a);
+    if (timing) { RT_HIP(hipEventRecord(e1, stream)); c->timed_gather.emplace_back(e0, e1); }
     c->gather_launches++;
     return rc;
+}
+
+// The gather of bounce b reads what the shade of bounce b queued and adds into the radiance of the paths; the traversal of
+// bounce b + 1 touches neither.  With a side stream at hand (the context's own streams: ensure_gather_side) the gather runs
+// there, beside that traversal, and the next kernel that reads or writes the paths' radiance or the gather queue -- the shade
+// of bounce b + 1, the next sample's bounce-0 shade, the resolve -- waits for it (gather_join).  Same kernels, same operands,
+// same order of the additions into every path: same bits.
+int gather_fork(rt_ctx* c, const PassArgs& a) {
+    hipStream_t side = c->gather_side && (c->stream == c->own_stream || c->stream == c->alt_stream) ? c->gather_stream[c->cur_lane] : nullptr;
+    if (!side) return timed_gather(c, a, c->stream);
+    RT_HIP(hipEventRecord(c->gather_ev[c->cur_lane][0], c->stream));
+    RT_HIP(hipStreamWaitEvent(side, c->gather_ev[c->cur_lane][0], 0));
+    int rc = timed_gather(c, a, side); if (rc) return rc;
+    RT_HIP(hipEventRecord(c->gather_ev[c->cur_lane][1], side));
+    c->gather_pending = true;
+    return RT_OK;
+}
+int gather_join(rt_ctx* c) {
+    if (!c->gather_pending) return RT_OK;
+    c->gather_pending = false;
+    RT_HIP(hipStreamWaitEvent(c->stream, c->gather_ev[c->cur_lane][1], 0));
+    return RT_OK;
+}
+int ensure_gather_side(rt_ctx* c, int lanes) {
+    for (int l = 0; l < lanes; l++) {
+        if (!c->gather_stream[l]) RT_HIP(hipStreamCreateWithFlags(&c->gather_stream[l], hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) if (!c->gather_ev[l][k]) RT_HIP(hipEventCreateWithFlags(&c->gather_ev[l][k], hipEventDisableTiming));
+    }
+    return RT_OK;
 }
 
 int drain_timers(rt_ctx* c) {
@@ -468,6 +501,11 @@ int run_pass(rt_ctx* c, bool probe) {
         for (u32 b = 0; b <= c->g.bounces_per_sample; b++) {
             bool primary = !probe && b == 0;
             if (primary && fused && a.fuse_primary) { rc = timed_primary_fused(c, a, s); if (rc) return rc; } // walk + shade in one kernel
+            else if (gather) { // (the gather of the bounce before may still run on its side stream: the traversal does not care, the shade waits)
+                rc = timed_traverse(c, a, b & 1u, primary, s); if (rc) return rc;
+                rc = gather_join(c); if (rc) return rc;
+                rc = launch_shade(c->stream, a, b & 1u, b, s, primary, fused); if (rc) return rc;
+            }
             else {
                 // the last bounce of the fused pass ends every path: its traversal kernel shades the hits itself (k_traverse, `tail`)
                 const bool tail_shade = c->fuse_tail && fused && !primary && !capture && b == c->g.bounces_per_sample && a.pool_groups == 0u && c->flat_instances != 2u &&
@@ -475,9 +513,10 @@ int run_pass(rt_ctx* c, bool probe) {
                 rc = timed_traverse(c, a, b & 1u, primary, s, tail_shade); if (rc) return rc;
                 if (!tail_shade) { rc = launch_shade(c->stream, a, b & 1u, b, s, primary, fused); if (rc) return rc; }
             }
-            if (gather && (int) b <= c->g.translucent_emission_bounces) { rc = timed_gather(c, a); if (rc) return rc; }
+            if (gather && (int) b <= c->g.translucent_emission_bounces) { rc = gather_fork(c, a); if (rc) return rc; }
         }
     }
+    { int jrc = gather_join(c); if (jrc) return jrc; } // (a sample whose last bounce gathers: nothing after it has waited yet)
     if (probe) return launch_probe_resolve(c->stream, a);
     if (fused && !c->defer_resolve) return RT_OK;
     // pipelined frames: pixels are added to in frame order, by the frame's resolve kernel alone; all the tracing, shading
@@ -698,6 +737,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
     if (const char* v = getenv("RT_FUSE_PRIMARY")) c->fuse_primary = atoi(v);
     if (const char* v = getenv("RT_FUSE_TAIL")) c->fuse_tail = atoi(v);
+    if (const char* v = getenv("RT_GATHER_SIDE")) c->gather_side = atoi(v);
     if (const char* v = getenv("RT_POOL")) c->pool = atoi(v);
     if (const char* v = getenv("RT_GATHER_L1")) c->gather_l1 = atoi(v);
     if (const char* v = getenv("RT_XCD_BANDS")) c->xcd_bands = atoi(v);
@@ -753,6 +793,8 @@ void rt_destroy(rt_ctx* c) {
     (void) drain_timers(c);
     dev_free(c->alt.d_arena); dev_free(c->alt.d_seg_count);
     if (c->alt_stream) (void) hipStreamDestroy(c->alt_stream);
+    for (int l = 0; l < 2; l++) { if (c->gather_stream[l]) { (void) hipStreamSynchronize(c->gather_stream[l]); (void) hipStreamDestroy(c->gather_stream[l]); }
+                                  for (int k = 0; k < 2; k++) if (c->gather_ev[l][k]) (void) hipEventDestroy(c->gather_ev[l][k]); }
     for (int k = 0; k < 2; k++) if (c->lane_done[k]) (void) hipEventDestroy(c->lane_done[k]);
     for (int k = 0; k < 2; k++) if (c->probe_done[k]) (void) hipEventDestroy(c->probe_done[k]);
     for (auto& b : c->blas) free_blas(b);
@@ -1299,9 +1341,12 @@ int rt_dispatch_rays(rt_ctx* c) {
             RT_HIP(hipStreamSynchronize(c->stream));
             int rc = ensure_path_buffers(c); if (rc) return rc;
             rc = ensure_second_lane(c); if (rc) return rc;
+            if (c->gather_side && gather) { rc = ensure_gather_side(c, 2); if (rc) return rc; }
             c->pipelined = true; c->next_lane = 0; c->have_previous = false; c->last_probe_lane = -1;
         }
         const int lane = c->next_lane;
+        if (c->gather_side && gather && !c->gather_stream[1]) { int grc = ensure_gather_side(c, 2); if (grc) return grc; } // (the gather came on after the lanes were made)
+        c->cur_lane = lane;
         auto swap_lane = [&]() { if (lane) { swap_path_buffers(c); std::swap(c->stream, c->alt_stream); std::swap(c->d_sp_read, c->d_sp_read_alt); std::swap(c->d_sp_pay, c->d_sp_pay_alt); } };
         swap_lane();
         int rc = RT_OK;
@@ -1320,6 +1365,7 @@ int rt_dispatch_rays(rt_ctx* c) {
         }
         if (rc == RT_OK) hip_ok(hipEventRecord(c->lane_done[lane], c->stream), "event record");
         swap_lane();
+        c->cur_lane = 0;
         if (rc) return rc;
         c->next_lane ^= 1; c->have_previous = true;
         c->dispatch_index++;
@@ -1330,6 +1376,8 @@ int rt_dispatch_rays(rt_ctx* c) {
     }
     int rc = quiesce(c); if (rc) return rc;
     rc = ensure_path_buffers(c); if (rc) return rc;
+    if (c->gather_side && gather && c->stream == c->own_stream) { rc = ensure_gather_side(c, 1); if (rc) return rc; }
+    c->cur_lane = 0;
     return dispatch_serial(c);
 }
 
@@ -1454,7 +1502,10 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
     out->primary_ms = c->traverse_primary_ms; out->rays_primary = c->primary_rays;
     out->bluenoise_ms = c->bluenoise_ms; out->bluenoise_points = c->bluenoise_points;
     out->tlas_depth = (u32) c->tlas_depth; out->max_blas_depth = (u32) c->max_blas_depth;
-    { PassArgs a; fill_pass_args(c, a, false); out->stack_in_lds = a.stack_in_lds; }
+    { PassArgs a; fill_pass_args(c, a, false); out->stack_in_lds = a.stack_in_lds;
+      const bool fused_pass = a.gather_enabled == 0u && !(c->flags & (RT_FLAG_COUNT_TRAVERSAL | RT_FLAG_CAPTURE_HITS));
+      out->fused_bounce0 = (fused_pass && a.fuse_primary) ? 1u : 0u;
+      out->fused_tail = (fused_pass && c->fuse_tail && a.pool_groups == 0u && c->flat_instances != 2u && c->persistent <= 0) ? 1u : 0u; }
     out->flat_depth = c->flat_instances ? (uint32_t) c->flat_info.depth : 0u;
     out->blas_build_ms = c->blas_build_ms; out->tlas_build_ms = c->tlas_build_ms;
     out->blas_triangles = c->blas_triangles; out->tlas_instances = c->n_instances;
