@@ -4,7 +4,9 @@ allows without changing any pixel's sample stream:
 
   tile split    (C4)  rank r renders the 32x32 tiles t with t % world == r; a pixel's RNG stream depends only on
                       (px, py, frame seed) (raytracing.hlsl:130), so each pixel is bit-identical to the 1-GPU render.
-                      Other ranks' pixels stay zero in the accumulator, so sum(all ranks) reproduces it exactly.
+                      Other ranks' pixels stay zero in the accumulator; the exchange is a gather of the tiles each rank
+                      owns (gather_tiles: 1 / world of the frame per rank, copied, not added), which reproduces it exactly
+                      (so would a reduce(sum) of the zero-filled frames, at world times the bytes).
                       The probe pass (translucent_rgen) is replicated on every rank: it is ~N_points*spp paths against
                       W*H*spp camera paths, and replication keeps sample-point payloads bit-identical without an exchange.
   sample split  (C5)  rank r renders frames r, r+world, ... of the frame_rng chain (main.cpp:443-454) into its own

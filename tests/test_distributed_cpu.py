@@ -16,11 +16,64 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+class _HostTiles(object):
+    """The tile entry points of the C-ABI (rt_tile_pack_bytes / rt_pack_tiles / rt_unpack_tiles, include/rt_abi.h) over a
+    host accumulator: local tile j of rank r is tile r + j * world of the image, 32x32 pixels of 16 bytes each, row-major
+    inside the tile, pixels beyond the image zero.  Stands in for the product so that distributed.gather_tiles -- the
+    exchange of the tile split -- runs under gloo on CPU."""
+
+    def __init__(self, acc):  # acc: (h, w, 4) float32, modified in place by unpack_tiles
+        self.acc = acc
+        self.h, self.w = acc.shape[:2]
+        self.tx, self.ty = (self.w + 31) // 32, (self.h + 31) // 32
+
+    def tile_pack_bytes(self, world):
+        return ((self.tx * self.ty + world - 1) // world) * 1024 * 16
+
+    def _view(self, ptr, world):
+        import ctypes
+        n = self.tile_pack_bytes(world) // 4
+        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_float)), shape=(n,)).reshape(-1, 32, 32, 4)
+
+    def _tiles(self, rank, world):
+        for j, t in enumerate(range(rank, self.tx * self.ty, world)):
+            y0, x0 = (t // self.tx) * 32, (t % self.tx) * 32
+            yield j, y0, x0, min(32, self.h - y0), min(32, self.w - x0)
+
+    def pack_tiles(self, rank, world, ptr):
+        v = self._view(ptr, world)
+        v[...] = 0.0
+        for j, y0, x0, hh, ww in self._tiles(rank, world):
+            v[j, :hh, :ww] = self.acc[y0:y0 + hh, x0:x0 + ww]
+
+    def unpack_tiles(self, rank, world, ptr):
+        v = self._view(ptr, world)
+        for j, y0, x0, hh, ww in self._tiles(rank, world):
+            self.acc[y0:y0 + hh, x0:x0 + ww] = v[j, :hh, :ww]
+
+    def sync(self):
+        pass
+
+
 def _worker(rank, world, port, mode, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle
     o = oracle.Oracle(brute_force=False, threads=2)
+    if mode == "tile_gather":
+        scene = scenes.cornell_bunny(96, 70, spp=2, bounces=2, sample_radius=0.06)
+        scene.setup(o)
+        o.set_tile_split(rank, world)
+        for f in range(2):
+            distributed.render_frame(o, scene.globals, f, 77)
+        acc = o.read_accumulator().copy()
+        nbytes = distributed.gather_tiles(_HostTiles(acc), dist, rank, world, torch.device("cpu"), dst=0, via_host=True)
+        assert nbytes == ((3 * 3 + world - 1) // world) * 16384   # 96x70 pixels = 3x3 tiles
+        if rank == 0:
+            np.save(os.path.join(out_dir, "acc.npy"), acc)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if mode == "tile":
         scene = scenes.cornell_bunny(96, 70, spp=2, bounces=2, sample_radius=0.06)
         scene.setup(o)
@@ -40,13 +93,28 @@ def _worker(rank, world, port, mode, out_dir):
     dist.destroy_process_group()
 
 
-def _run(mode, tmp_path):
-    mp.spawn(_worker, args=(2, _free_port(), mode, str(tmp_path)), nprocs=2, join=True)
+def _run(mode, tmp_path, world=2):
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
     return np.load(os.path.join(str(tmp_path), "acc.npy"))
 
 
 def test_tile_split_is_bit_exact(tmp_path, oracle_mod):
     got = _run("tile", tmp_path)
+    o = oracle_mod.Oracle(brute_force=False, threads=4)
+    scene = scenes.cornell_bunny(96, 70, spp=2, bounces=2, sample_radius=0.06)
+    scene.setup(o)
+    for f in range(2):
+        distributed.render_frame(o, scene.globals, f, 77)
+    want = o.read_accumulator()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    o.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_split_by_gather_of_owned_tiles_is_bit_exact(tmp_path, oracle_mod, world):
+    """distributed.gather_tiles, the exchange bench.py --split tile uses: every rank packs the tiles it owns, rank 0 gathers
+    and unpacks them (9 tiles over 2 or 3 ranks: unequal shares, padded tiles at the right and bottom edges)"""
+    got = _run("tile_gather", tmp_path, world)
     o = oracle_mod.Oracle(brute_force=False, threads=4)
     scene = scenes.cornell_bunny(96, 70, spp=2, bounces=2, sample_radius=0.06)
     scene.setup(o)
