@@ -55,3 +55,18 @@ def test_rt_create_fails_loudly_without_a_gpu():
     from raytracer_amd import api
     with pytest.raises(RuntimeError):
         api.Raytracer(0)
+
+
+def test_committed_counter_passes_belong_to_the_committed_kernel_sources():
+    """bench.py prices its roofline with the PMC passes in profiles/pmc_traffic.json and drops them (roofline.frac = null,
+    pmc_note says why) when they were taken on other kernel sources: after a change under raytracer_amd/csrc, include/rt_abi.h
+    or the Makefile, rerun tools/final_measure.sh pmc (GPU) and tools/pmc_merge.py before committing."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import pmc_summary
+    want = pmc_summary.source_hash(root)
+    entries = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    for key in ("c2", "c3", "c4", "c5", "c5_3840x2160"):
+        assert entries[key]["source_hash"] == want, "profiles/pmc_traffic.json[%r] is stale (%s, sources are %s)" % (key, entries[key]["source_hash"], want)
