@@ -11,8 +11,10 @@ N > 1 (launched by torch.distributed.run, one rank per GPU), full scene replica 
                                 is fixed => "scaling": "weak".
   --split tile   (default for --workload c4)  every rank renders every frame, but only the 32x32 tiles t with
                                 t % N == r (rt_set_tile_split); total work is fixed => "scaling": "strong".
-Either way no collective runs during the K steps; one RCCL reduce(sum) of the RGBA32F accumulators to rank 0 closes
-the timed region (its duration is reported separately as `reduce_ms`).
+Either way no collective runs during the K steps; one exchange closes the job -- RCCL reduce(sum) of the RGBA32F
+accumulators to rank 0 (sample split) or a gather of the tiles each rank owns (tile split) -- and is part of the timed job
+(`reduce_ms`).  When a block of K steps is shorter than 50 ms, R blocks are timed and the median reported (`timed_blocks`);
+the job is then R x K frames with ONE exchange, and a block carries reduce_ms / R (`exchange.ms_charged_per_block`).
 
 The JSON line also carries
   roofline:     the dominant kernel (k_traverse).  What bounds it is vector-instruction issue, not HBM (the scenes are
@@ -270,7 +272,9 @@ def main():
             exchange_bytes = acc.numel() * 4
     fence()
     reduce_ms = (time.perf_counter() - t_x) * 1e3 if dist is not None else 0.0   # this rank's wait for the slowest rank included
-    dt = dt_block + reduce_ms * 1e-3
+    # The job that ran is len(block_s) blocks of K frames and ONE exchange after its last frame; a block's share of it is
+    # reduce_ms / blocks (with one block -- every run of 50 ms or more per block -- the whole exchange is in `dt`)
+    dt = dt_block + reduce_ms * 1e-3 / len(block_s)
     if args.dump_accumulator and rank == 0:
         import numpy as np
         np.save(args.dump_accumulator, acc.cpu().numpy().reshape(args.height, args.width, 4))
@@ -360,7 +364,11 @@ def main():
         # another build's instruction count with this build's timing.
         pmc_all, pmc, pmc_note = None, None, None
         key = pmc_key(args)
-        if world == 1:
+        # (N > 1: under the sample-set split rank 0 runs the one-GPU frames, so the one-GPU passes describe its launches; the
+        # tile split's launches are 1 / N of them, and ranks that rehearse on one GPU share it)
+        if world > 1 and (tile or args.rehearse):
+            pmc_note = "the committed PMC passes are of one-GPU launches: not applicable to %s" % ("ranks sharing one GPU (--rehearse)" if args.rehearse else "the tile split's 1/N-size launches")
+        else:
             try:
                 entry = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[key]
                 if entry.get("source_hash") != pmc_summary.source_hash(ROOT):
@@ -444,7 +452,7 @@ def main():
             "value": total_rays / dt_max / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll_steps,
-            "timed_blocks": n_blocks, "block_ms": [round(b * 1e3, 4) for b in block_s],   # value: the median block (+ the exchange)
+            "timed_blocks": n_blocks, "block_ms": [round(b * 1e3, 4) for b in block_s],   # value: the median block (+ its share of the one exchange)
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if tile else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -457,7 +465,9 @@ def main():
             "secondary_Mrays_s": secondary,    # queued launches alone (scattered / sample-point rays: incoherent)
             "reduce_ms": reduce_ms if world > 1 else None,   # the one exchange step, part of the timed job (rank 0's view)
             "exchange": None if world == 1 else {"kind": "gather of owned tiles" if tile else "reduce(sum) of the accumulator",
-                                                 "bytes_per_rank": exchange_bytes},
+                                                 "bytes_per_rank": exchange_bytes,
+                                                 # one exchange per job of timed_blocks x steps frames: a block carries its share
+                                                 "per_job_of_frames": n_blocks * args.steps, "ms_charged_per_block": reduce_ms / n_blocks},
             "roofline": {"bound": "valu_issue", "kernel": "k_traverse", "achieved": achieved, "peak": peak, "unit": "Ginst/s",
                          "frac": frac, "traffic": traffic, "traffic_frac": traffic_frac, "pmc_entry": key, "pmc_note": pmc_note,
                          "valu_insts_per_launch": insts, "cycles_per_inst_best": cyc_best, "cycles_per_inst_node_step_mix": cyc_mix,
