@@ -245,8 +245,9 @@ def main():
         for _ in range(args.steps):
             step(True)
         rt.sync()
+        t1 = time.perf_counter()   # this rank's K steps are done; the closing fence's own latency (a barrier over N ranks) is not a step
         fence()
-        d = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        d = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
         if dist is not None:
             dist.all_reduce(d, op=dist.ReduceOp.MAX)     # the slowest rank's block (outside the timed window)
         return float(d.item())
