@@ -29,6 +29,19 @@ namespace rtd {
 
 typedef uint32_t u32;
 
+// wave votes.  The ballot of a compare IS the compare's lane mask; the ballot of a conjunction of two compares is lowered as
+// v_cndmask 0, 1 + v_cmp_ne (two vector instructions per vote, in the hottest loop of the flat walk): any_lane_both takes the
+// two ballots and combines them as scalars instead.
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_DEV bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+RT_DEV bool all_lanes(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+RT_DEV bool any_lane_both(bool p, bool q) { return (__builtin_amdgcn_ballot_w64(p) & __builtin_amdgcn_ballot_w64(q)) != 0ull; }
+#else
+RT_DEV bool any_lane(bool p) { return p; }
+RT_DEV bool all_lanes(bool p) { return p; }
+RT_DEV bool any_lane_both(bool p, bool q) { return p && q; }
+#endif
+
 struct f3 { float x, y, z; };
 
 RT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -176,7 +189,7 @@ RT_DEV RayPrep prepare_ray(f3 o, f3 d) {
     // Same-box A/B (profiles/r02_ab_shared_divisor.txt): C2 +1.0 %, C3 +0.45 %; at the instance entries of the two-level walk,
     // where a few lanes of a wave prepare at a time, the vote costs more than the divisions saved (C5 -0.3 %): not used there.
     const float small = fminf(fabsf(d1), fabsf(d2));
-    if (SHARED_DIVISOR && __all(fabsf(dz) <= 0x1p60f && small >= 0x1p-60f)) {
+    if (SHARED_DIVISOR && all_lanes(fabsf(dz) <= 0x1p60f && small >= 0x1p-60f)) {
         float rc = __builtin_amdgcn_rcpf(dz);
         rc = __builtin_fmaf(__builtin_fmaf(-dz, rc, 1.0f), rc, rc);
         float q = d1 * rc;

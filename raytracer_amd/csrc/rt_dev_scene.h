@@ -317,7 +317,7 @@ RT_DEV void inlined_triangles_first(const SceneView& sc, f3 o, f3 d, float tmin,
                 const float ex = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), best.t));
                 in_box = en <= __builtin_fmaf(1.0e-5f, fabsf(en) + fabsf(ex), ex); // [tmin, closest hit so far] of the ray against the box, with slack
             }
-            if (__any(in_box)) need |= 1u << j;
+            if (any_lane(in_box)) need |= 1u << j;
         }
     }
     if (need == 0u) return;
@@ -367,8 +367,8 @@ RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, S
             // ---- BLAS leaf: up to 8 triangles ------------------------------------------------------------------
             int v = ~S.cur;
             int first = v >> 3, count = (v & 7) + 1;
-            for (int k = 0; k < count; k++) {
-                const RT_GLOBAL TriRec* tr = S.tris + first + k;
+            const RT_GLOBAL TriRec* tr = S.tris + first;
+            for (int k = 0; k < count; k++, tr++) {
                 Quad a = ldq(tr, 0), b = ldq(tr, 1), c = ldq(tr, 2);
                 if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
                 triangle_candidate(S.rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), tmin, S.cur_inst, first + k, as_u32(c.y), S.ch);
@@ -432,7 +432,7 @@ RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, 
     for (int i = 0; i < K; i++) {
         RayPrep& rp = preps.rp[i];
         rp.o = mk3(0.0f, 0.0f, 0.0f); rp.kz = 0; rp.flip = 0u; rp.sx = 0.0f; rp.sy = 0.0f; rp.sz = 0.0f;
-        if ((K > 1 || INL) && !__any(enters[i])) continue; // wave-uniform
+        if ((K > 1 || INL) && !any_lane(enters[i])) continue; // wave-uniform
         // the matrices are kernel arguments (scalar loads); CAMERA_ORIGIN: o is the camera's for every lane and the host has transformed it
         const f3 oo = CAMERA_ORIGIN ? mk3(sc.flat_cam_o[i][0], sc.flat_cam_o[i][1], sc.flat_cam_o[i][2]) : xform_point43(sc.flat_w2o[i], o);
         rp = prepare_ray<true>(oo, xform_dir43(sc.flat_w2o[i], d));
@@ -451,8 +451,9 @@ RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, 
             // nodes per ray 6.73 -> 6.83).  Coherent rays reach their leaves together and only pay the vote: PRIMARY launches
             // walk without it.
             for (;;) {
-                const bool need = pending == RT_TRAVERSAL_DONE && cur != RT_TRAVERSAL_DONE;
-                if (!__any(need)) break;
+                const bool none_aside = pending == RT_TRAVERSAL_DONE, walking = cur != RT_TRAVERSAL_DONE;
+                const bool need = none_aside && walking;
+                if (!any_lane_both(none_aside, walking)) break;
                 if (cur >= 0) cur = node_step<Stack, COUNT, true>(nodes, br, cur, tmin, best.t, st, cnt);
                 else if (need) { pending = cur; cur = st.pop(); }
             }
@@ -468,9 +469,11 @@ RT_DEV void trace_flat(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, 
         const u32 first = v >> 3, count = (v & 7u) + 1u;
         const u32 inst = K > 1 ? (first >= sc.flat_first1 ? 1u : 0u) : (INL ? sc.flat_inst0 : 0u);
         const RayPrep rp = flat_pick<K>(preps, K > 1 ? inst : 0u);
-        const RT_GLOBAL char* tris0 = (const RT_GLOBAL char*) sc.flat_tris + ((size_t) first * sizeof(FlatTri) + (size_t) ((u32) rp.kz * sc.flat_copy_bytes));
+        // the three copies are < 2^32 bytes together: the triangle's address is the array's (scalar) base + a 32-bit offset, like the node's
+        static_assert((unsigned long long) RT_FLAT_MAX_TRIS * sizeof(FlatTri) * 3ull < (1ull << 32), "32-bit triangle offsets");
+        const u32 off0 = __umul24(first, (u32) sizeof(FlatTri)) + (u32) rp.kz * sc.flat_copy_bytes; // first < 2^20: a 24-bit multiply-add
         for (u32 k = 0; k < count; k++) {
-            const RT_GLOBAL FlatTri* tr = (const RT_GLOBAL FlatTri*) (tris0 + k * sizeof(FlatTri));
+            const RT_GLOBAL FlatTri* tr = (const RT_GLOBAL FlatTri*) ((const RT_GLOBAL char*) sc.flat_tris + (unsigned long long) (off0 + k * (u32) sizeof(FlatTri)));
             const Quad a = ldq(tr, 0), b = ldq(tr, 1), c = ldq(tr, 2);
             if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
             triangle_candidate(rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), tmin, (int) inst, (int) as_u32(c.z), as_u32(c.y), best);

@@ -1405,7 +1405,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
                 auto dist2 = [&](u32 k) -> float { const const_floats sp = spos + 4u * k; f3 dp = mk3(sp[0], sp[1], sp[2]) - hit; return dot3(dp, dp); };
                 u32 k = 0;
                 for (; k + 4 <= nk; k += 4) {
-                    if ((MODE == 1 || MODE == 3) && __all(fminf(fminf(dist2(k), dist2(k + 1)), fminf(dist2(k + 2), dist2(k + 3))) >= cut2)) continue;
+                    if ((MODE == 1 || MODE == 3) && all_lanes(fminf(fminf(dist2(k), dist2(k + 1)), fminf(dist2(k + 2), dist2(k + 3))) >= cut2)) continue;
                     Term c0 = term(k), c1 = term(k + 1), c2 = term(k + 2), c3 = term(k + 3);
                     add(c0); add(c1); add(c2); add(c3);
                 }
