@@ -154,6 +154,8 @@ typedef struct RtStats {
     uint32_t fused_bounce0;           /* 1 = camera dispatches without the BSSRDF gather walk AND shade bounce 0 in one kernel (flat one-instance */
                                       /* scenes): that launch is counted in primary_launches / primary_ms, and no separate bounce-0 shade runs   */
     uint32_t fused_tail;              /* 1 = their last bounce is shaded inside its traversal kernel                                             */
+    uint32_t tlas_grid_cells;         /* > 0: the top level of a two-level scene is walked as a uniform grid of that many cells (many evenly spread   */
+                                      /* instances: the 52,743-instance field), the top-level tree stays for the other kernels; RT_TLAS_GRID=0: never */
 } RtStats;
 
 /* rt_set_flags bits */

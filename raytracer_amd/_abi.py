@@ -70,7 +70,7 @@ class RtStats(C.Structure):
                 ("primary_launches", C.c_uint64), ("primary_launches_timed", C.c_uint64), ("primary_ms", C.c_double),
                 ("rays_primary", C.c_uint64), ("bluenoise_ms", C.c_double), ("bluenoise_points", C.c_uint64),
                 ("tlas_depth", C.c_uint32), ("max_blas_depth", C.c_uint32), ("stack_in_lds", C.c_uint32), ("flat_depth", C.c_uint32),
-                ("fused_bounce0", C.c_uint32), ("fused_tail", C.c_uint32)]
+                ("fused_bounce0", C.c_uint32), ("fused_tail", C.c_uint32), ("tlas_grid_cells", C.c_uint32)]
 
 
 def load_library(path):

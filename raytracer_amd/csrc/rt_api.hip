@@ -97,6 +97,9 @@ struct rt_ctx {
     u32 n_paths = 0; float* d_arena = nullptr;
     RayQueue q[2]; HitBuf hits; PathState ps; SlotState st[2]; GatherQueue gq; int* d_stack_spill = nullptr;
     u32* d_task_counter = nullptr; u32 persistent_slots = 0; int persistent = 0; // RT_PERSISTENT: 0 never (default), bit 0 queued launches, bit 1 primary launches
+    // grid top level (SceneView::grid_*, trace_run_grid): RT_TLAS_GRID = 0 never, 1 where the instances suit it (default), 2 wherever the stacks allow
+    int tlas_grid = 0; u32* d_grid_start = nullptr; GridEntry* d_grid_entries = nullptr;
+    u32 grid_cells = 0, grid_n_entries = 0, grid_res[3] = { 0, 0, 0 }; float grid_lo[3] = {}, grid_cell[3] = {}, grid_slack = 0.0f, grid_density = 1.0f;
     int pool = 0; u32 cu_count = 0; // RT_POOL=2: pooled traversal for the queued launches of two-level scenes (rt_dev_pool.h), workgroups per CU; off by default (profiles/r03_ab_pool_c5.txt: right, and 2-4x slower)
     // the BSSRDF gather of a bounce on a side stream, beside the next bounce's traversal (run_pass): one side stream and two
     // events per lane, made with the lane (ensure_gather_side); RT_GATHER_SIDE=1 -- measured, not kept (profiles/r03_ab_gather_side.txt): default in stream order
@@ -324,6 +327,10 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     memcpy(a.scene.inl_box, c->inl_box, sizeof c->inl_box); a.scene.inl_box_same = c->inl_box_same;
     for (int k = 0; k < 3; k++) { const float* m = c->inl_w2o; const float* p = a.camera_origin; a.scene.inl_cam_o[k] = p[0] * m[k] + p[1] * m[3 + k] + p[2] * m[6 + k] + m[9 + k]; } // xform_point43, operation for operation
     a.scene.flat_instances = c->flat_instances;
+    a.scene.grid_cells = (c->flat_instances || c->persistent > 0) ? 0u : c->grid_cells; a.scene.grid_n_entries = c->grid_n_entries;
+    a.scene.grid_start = c->d_grid_start; a.scene.grid_entries = c->d_grid_entries;
+    for (int k = 0; k < 3; k++) { a.scene.grid_res[k] = c->grid_res[k]; a.scene.grid_lo[k] = c->grid_lo[k]; a.scene.grid_cell[k] = c->grid_cell[k]; a.scene.grid_inv_cell[k] = c->grid_cell[k] > 0.0f ? 1.0f / c->grid_cell[k] : 0.0f; }
+    a.scene.grid_slack = c->grid_slack;
     a.flat_waves8 = (c->flat_waves8 && c->flat_instances == 1 && c->flat_info.depth + 2 <= 20) ? 1u : 0u;
     a.flat_waves7 = (c->flat_waves7 && c->flat_instances == 2 && c->flat_info.depth + 2 <= 22) ? 1u : 0u; // the two-instance kernels fit 72 VGPRs since the ray preparation moved behind the root step
     if (c->flat_instances) {
@@ -590,6 +597,106 @@ int set_inline_boxes(rt_ctx* c, const Blas& b, const float* o2w) {
     return RT_OK;
 }
 
+void free_tlas_grid(rt_ctx* c) {
+    dev_free(c->d_grid_start); dev_free(c->d_grid_entries);
+    c->grid_cells = 0; c->grid_n_entries = 0;
+}
+
+// Grid top level (rt_dev_scene.h, trace_run_grid): a uniform grid over the world boxes of the top level's n_prims instances
+// (lbvh.boxes, as rt_build_tlas left them: slot inl_inst holds the last instance).  Built on the host from the boxes the GPU
+// computed; cell size from the number of instances (grid_density cells per instance), axes along which the instances do
+// not spread get one cell.  Scenes it does not suit keep the tree alone: few instances, instances that span many cells
+// (mode 1), bottom-level trees too deep for the grid kernels' stack rows.
+int build_tlas_grid(rt_ctx* c, u32 n, u32 n_prims, int max_blas_depth) {
+    free_tlas_grid(c);
+    if (c->tlas_grid <= 0 || n_prims < 2) return RT_OK;
+    if (max_blas_depth + 2 > RT_GRID_STACK_ROWS) return RT_OK;
+    if (c->tlas_grid == 1 && n_prims < 4096) return RT_OK;
+    const auto t_begin = std::chrono::steady_clock::now();
+    std::vector<Aabb> box(n_prims);
+    RT_HIP(hipMemcpy(box.data(), c->lbvh.boxes, sizeof(Aabb) * n_prims, hipMemcpyDeviceToHost));
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    u32 valid = 0;
+    for (u32 p = 0; p < n_prims; p++) {
+        const Aabb& b = box[p];
+        bool ok = true;
+        for (int k = 0; k < 3; k++) ok = ok && b.lo[k] <= b.hi[k] && fabsf(b.lo[k]) < 1.0e30f && fabsf(b.hi[k]) < 1.0e30f;
+        if (!ok) continue; // an instance without triangles: in no cell
+        valid++;
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double) b.lo[k]); hi[k] = std::max(hi[k], (double) b.hi[k]); }
+    }
+    if (valid < 2) return RT_OK;
+    double e[3], diag2 = 0.0, maxabs = 0.0;
+    for (int k = 0; k < 3; k++) { e[k] = hi[k] - lo[k]; diag2 += e[k] * e[k]; maxabs = std::max(maxabs, std::max(fabs(lo[k]), fabs(hi[k]))); }
+    const double slack = 2.0e-5 * (sqrt(diag2) + maxabs);
+    if (!(slack > 0.0)) return RT_OK;
+    for (int k = 0; k < 3; k++) { lo[k] -= 2.0 * slack; hi[k] += 2.0 * slack; e[k] = hi[k] - lo[k]; }
+    // cell size: `cells` cells over the axes along which the instances spread
+    const double cells = (double) valid * c->grid_density;
+    bool thin[3] = { false, false, false };
+    double size = 0.0;
+    for (int iter = 0; iter < 3; iter++) {
+        int m = 0; double vol = 1.0;
+        for (int k = 0; k < 3; k++) if (!thin[k]) { m++; vol *= e[k]; }
+        size = m == 3 ? cbrt(vol / cells) : m == 2 ? sqrt(vol / cells) : vol / cells;
+        bool changed = false;
+        for (int k = 0; k < 3; k++) if (!thin[k] && m > 1 && e[k] < 1.5 * size) { thin[k] = true; changed = true; break; } // one axis at a time, thinnest first below
+        if (!changed) break;
+    }
+    u32 res[3]; double cell[3];
+    for (int k = 0; k < 3; k++) {
+        res[k] = thin[k] ? 1u : (u32) std::min(std::max(ceil(e[k] / size), 1.0), (double) RT_GRID_MAX_RES);
+        cell[k] = e[k] / (double) res[k];
+    }
+    const uint64_t n_cells = (uint64_t) res[0] * res[1] * res[2];
+    if (n_cells > (64ull << 20)) return RT_OK;
+    // cells of each instance's grown box
+    auto cell_range = [&](const Aabb& b, int k, u32& c0, u32& c1) {
+        const double a = ((double) b.lo[k] - slack - lo[k]) / cell[k], z = ((double) b.hi[k] + slack - lo[k]) / cell[k];
+        c0 = (u32) std::min(std::max(floor(a), 0.0), (double) (res[k] - 1));
+        c1 = (u32) std::min(std::max(floor(z), 0.0), (double) (res[k] - 1));
+    };
+    std::vector<u32> start(n_cells + 1, 0u);
+    uint64_t total = 0;
+    for (u32 p = 0; p < n_prims; p++) {
+        const Aabb& b = box[p];
+        if (!(b.lo[0] <= b.hi[0] && b.lo[1] <= b.hi[1] && b.lo[2] <= b.hi[2]) || !(fabsf(b.lo[0]) < 1.0e30f)) continue;
+        u32 c0[3], c1[3];
+        for (int k = 0; k < 3; k++) cell_range(b, k, c0[k], c1[k]);
+        const uint64_t span = (uint64_t) (c1[0] - c0[0] + 1) * (c1[1] - c0[1] + 1) * (c1[2] - c0[2] + 1);
+        if (c->tlas_grid == 1 && span > 64) return RT_OK; // an instance much larger than the others: the tree handles it better
+        total += span;
+        if (total > (1ull << 28)) return RT_OK;
+        for (u32 z = c0[2]; z <= c1[2]; z++) for (u32 y = c0[1]; y <= c1[1]; y++) for (u32 x = c0[0]; x <= c1[0]; x++)
+            start[((uint64_t) z * res[1] + y) * res[0] + x + 1] += 1u;
+    }
+    if (total == 0 || (c->tlas_grid == 1 && total > 8ull * valid)) return RT_OK;
+    for (uint64_t i = 0; i < n_cells; i++) start[i + 1] += start[i];
+    std::vector<GridEntry> entries(total);
+    std::vector<u32> fill(start.begin(), start.end() - 1);
+    for (u32 p = 0; p < n_prims; p++) {
+        const Aabb& b = box[p];
+        if (!(b.lo[0] <= b.hi[0] && b.lo[1] <= b.hi[1] && b.lo[2] <= b.hi[2]) || !(fabsf(b.lo[0]) < 1.0e30f)) continue;
+        u32 c0[3], c1[3];
+        for (int k = 0; k < 3; k++) cell_range(b, k, c0[k], c1[k]);
+        GridEntry en;
+        for (int k = 0; k < 3; k++) { en.lo[k] = (float) ((double) b.lo[k] - slack); en.hi[k] = (float) ((double) b.hi[k] + slack); }
+        en.inst = (c->inl_inst >= 0 && (int) p == c->inl_inst) ? n - 1u : p; // the slot of the inlined instance holds the last one
+        en.pad = 0u;
+        for (u32 z = c0[2]; z <= c1[2]; z++) for (u32 y = c0[1]; y <= c1[1]; y++) for (u32 x = c0[0]; x <= c1[0]; x++)
+            entries[fill[((uint64_t) z * res[1] + y) * res[0] + x]++] = en;
+    }
+    RT_HIP(hipMalloc(&c->d_grid_start, sizeof(u32) * (n_cells + 1)));
+    RT_HIP(hipMalloc(&c->d_grid_entries, sizeof(GridEntry) * total));
+    RT_HIP(hipMemcpy(c->d_grid_start, start.data(), sizeof(u32) * (n_cells + 1), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(c->d_grid_entries, entries.data(), sizeof(GridEntry) * total, hipMemcpyHostToDevice));
+    for (int k = 0; k < 3; k++) { c->grid_res[k] = res[k]; c->grid_lo[k] = (float) lo[k]; c->grid_cell[k] = (float) cell[k]; }
+    c->grid_slack = (float) slack;
+    c->grid_cells = (u32) n_cells; c->grid_n_entries = (u32) total;
+    c->tlas_build_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return RT_OK;
+}
+
 void free_flat_tree(rt_ctx* c) {
     c->flat_inl_inst = -1; c->flat_inst0 = 0;
     dev_free(c->d_flat_nodes); c->d_flat_tris = nullptr; dev_free(c->d_flat_perm);
@@ -744,6 +851,8 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_SORT_BOX")) c->sort_box = atoi(v);
     if (const char* v = getenv("RT_SORT_CHORD")) c->sort_chord_pct = (float) atof(v);
     if (const char* v = getenv("RT_INLINE")) c->inline_enabled = atoi(v) != 0;
+    if (const char* v = getenv("RT_TLAS_GRID")) c->tlas_grid = atoi(v);
+    if (const char* v = getenv("RT_GRID_DENSITY")) { c->grid_density = (float) atof(v); if (!(c->grid_density > 0.01f && c->grid_density < 100.0f)) c->grid_density = 1.0f; }
     if (const char* v = getenv("RT_FLAT_INLINE")) c->flat_inline_enabled = atoi(v) != 0;
     if (const char* v = getenv("RT_PERSISTENT")) c->persistent = atoi(v);
     if (const char* v = getenv("RT_STACK_LDS")) c->stack_lds_ok = atoi(v) != 0;
@@ -801,7 +910,7 @@ void rt_destroy(rt_ctx* c) {
     for (auto& m : c->translucent_meshes) dev_free(m.d_partial_areas);
     free_sample_points(c);
     dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
-    free_flat_tree(c);
+    free_flat_tree(c); free_tlas_grid(c);
     dev_free(c->d_task_counter);
     dev_free(c->d_accumulator); dev_free(c->d_render_target); dev_free(c->d_capture); dev_free(c->d_arena);
     dev_free(c->d_seg_count); dev_free(c->d_stats); dev_free(c->d_table[0]); dev_free(c->d_table[1]); dev_free(c->d_gather_delta);
@@ -973,7 +1082,7 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
         max_blas_depth = std::max(max_blas_depth, b.depth);
     }
     dev_free(c->d_inst_rec); dev_free(c->d_inst_shade); dev_free(c->d_tlas_nodes); dev_free(c->d_tlas_perm);
-    free_flat_tree(c);
+    free_flat_tree(c); free_tlas_grid(c);
     c->n_instances = 0; c->tlas_depth = 0; // no top level until this call has succeeded: a failure below leaves rt_dispatch_rays answering RT_ERR_STATE
     // the instance to inline (SceneView::inl_inst): among those of at most RT_INLINE_MAX_TRIS triangles the one that reaches
     // furthest (a floor under 50,000 meshes, a room around them); scenes that get a flat tree have no use for it
@@ -1024,6 +1133,7 @@ int rt_build_tlas(rt_ctx* c, const RtInstance* instances, int n) {
     rc = build_flat_tree(c, instances, n, rec);
     if (rc != RT_OK) { free_flat_tree(c); return rc; }
     c->tlas_build_ms += c->flat_build_ms;
+    if (!c->flat_instances) { rc = build_tlas_grid(c, (u32) n, n_prims, max_blas_depth); if (rc != RT_OK) { free_tlas_grid(c); return rc; } }
     c->tlas_depth = c->tlas_info.depth; c->max_blas_depth = max_blas_depth;
     c->n_instances = (u32) n;
     return RT_OK;
@@ -1502,6 +1612,7 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
     out->primary_ms = c->traverse_primary_ms; out->rays_primary = c->primary_rays;
     out->bluenoise_ms = c->bluenoise_ms; out->bluenoise_points = c->bluenoise_points;
     out->tlas_depth = (u32) c->tlas_depth; out->max_blas_depth = (u32) c->max_blas_depth;
+    out->tlas_grid_cells = (c->flat_instances || c->persistent > 0) ? 0u : c->grid_cells;
     { PassArgs a; fill_pass_args(c, a, false); out->stack_in_lds = a.stack_in_lds;
       const bool fused_pass = a.gather_enabled == 0u && !(c->flags & (RT_FLAG_COUNT_TRAVERSAL | RT_FLAG_CAPTURE_HITS));
       out->fused_bounce0 = (fused_pass && a.fuse_primary) ? 1u : 0u;

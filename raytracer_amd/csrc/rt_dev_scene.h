@@ -78,6 +78,16 @@ struct alignas(16) FlatTri {
 #define RT_FLAT_MAX_INSTANCES 2
 #define RT_FLAT_MAX_TRIS (1u << 20) // triangles of all instances together (leaf links keep 24 bits for the first one)
 
+// Grid top level (rt_api.hip build_tlas_grid): scenes of many instances of similar size spread evenly (the 52,743-instance
+// field) get, besides the top-level tree, a uniform grid over the instances' world boxes; cell c lists the instances whose
+// box (grown by grid_slack) overlaps it, entries grid_start[c] .. grid_start[c + 1].  32 B, fetched as 2 x 16 B.
+struct alignas(16) GridEntry {
+    float lo[3]; u32 inst;   // index into the rt_build_tlas array
+    float hi[3]; u32 pad;
+};
+#define RT_GRID_MAX_RES 1024
+#define RT_GRID_STACK_ROWS 20    // LDS stack rows of the grid kernels: sentinel + bottom-level depth + the row above the top
+
 #define RT_INLINE_MAX_TRIS 8
 struct SceneView {
     const PackedNode* tlas_nodes;
@@ -114,6 +124,13 @@ struct SceneView {
     float flat_ctr[3], flat_inv_h[3], flat_bound;
     float flat_w2o[RT_FLAT_MAX_INSTANCES][12]; // world_to_object of the instances (InstRec), here so that they arrive as scalars
     float flat_cam_o[RT_FLAT_MAX_INSTANCES][3]; // the camera origin in the object space of each instance (xform_point43 done by the host: same operations, same result)
+    // grid top level (grid_cells = 0: none, walk tlas_nodes): see GridEntry / trace_run_grid
+    const u32* grid_start;       // [cells + 1] first entry of each cell
+    const GridEntry* grid_entries;
+    u32 grid_cells, grid_n_entries;
+    u32 grid_res[3];             // cells per axis, each 1 .. RT_GRID_MAX_RES
+    float grid_lo[3], grid_cell[3], grid_inv_cell[3];
+    float grid_slack;            // world-space slack of the grid's decisions (the entries' boxes are grown by it)
 };
 
 struct HitOut {
@@ -245,11 +262,15 @@ RT_DEV void trace_resume_top_level(const SceneView& sc, const Stack& st, TraceSt
     b.px = b.idx >= 0.0f; b.py = b.idy >= 0.0f; b.pz = b.idz >= 0.0f;
 }
 
-RT_DEV void trace_begin(const SceneView& sc, f3 o, f3 d, float tmax, TraceState& S) {
+RT_DEV void trace_begin(const SceneView& sc, f3 o, f3 d, float tmax, TraceState& S, bool tree_top_level = true) {
     S.ch.t = tmax; S.ch.u_num = 0.0f; S.ch.v_num = 0.0f; S.ch.det = 1.0f; S.ch.inst = -1; S.ch.tri = -1; S.ch.prim_global = 0;
     S.cur_inst = -1; S.tris = nullptr;
     S.rp.o = o; S.rp.kz = 2; S.rp.flip = 0u; S.rp.sx = S.rp.sy = S.rp.sz = 0.0f;
-    trace_top_level(sc, o, d, S);
+    if (tree_top_level) trace_top_level(sc, o, d, S);
+    else { // grid top level (trace_run_grid): no box-test constants for the world-space ray
+        S.bottom = false; S.nodes = nullptr;
+        S.br.idx = S.br.idy = S.br.idz = 1.0f; S.br.cnx = S.br.cny = S.br.cnz = 0.0f; S.br.cfx = S.br.cfy = S.br.cfz = 0.0f; S.br.px = S.br.py = S.br.pz = true;
+    }
     // a NaN in the ray makes every triangle test fail (S4 compares with NaN are false): the answer is a miss, and
     // it must not cost a walk through the whole tree (NaN box tests pass conservatively).  Such rays do occur:
     // a shading normal perpendicular to the ray is scaled by sign(0) = 0 (raytracing.hlsl:64-65).
@@ -363,6 +384,160 @@ RT_DEV void trace_run(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, S
             trace_bottom_level(sc, o, d, S);
             st.push(RT_STACK_MARKER);
             S.cur = 0;
+        } else {
+            // ---- BLAS leaf: up to 8 triangles ------------------------------------------------------------------
+            int v = ~S.cur;
+            int first = v >> 3, count = (v & 7) + 1;
+            const RT_GLOBAL TriRec* tr = S.tris + first;
+            for (int k = 0; k < count; k++, tr++) {
+                Quad a = ldq(tr, 0), b = ldq(tr, 1), c = ldq(tr, 2);
+                if (COUNT) { cnt.tris++; if (first_active_lane()) cnt.tri_trips++; }
+                triangle_candidate(S.rp, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), tmin, S.cur_inst, first + k, as_u32(c.y), S.ch);
+            }
+            S.cur = st.pop();
+        }
+    }
+    S.best.inst = S.ch.inst; S.best.tri = S.ch.tri; S.best.prim_global = S.ch.prim_global;
+    if (S.ch.inst >= 0) { S.best.t = S.ch.t; S.best.u = S.ch.u_num / S.ch.det; S.best.v = S.ch.v_num / S.ch.det; } // S4: u = V / det, v = W / det
+    else { S.best.t = inf_f32(); S.best.u = 0.0f; S.best.v = 0.0f; }
+}
+
+// ---- two-level scenes with a grid top level -------------------------------------------------------------------------------
+// The same closest hit as trace_run; the top level is walked as a uniform grid instead of a tree.  A ray in a tree over
+// 52,743 instances takes 17 of its 29 node steps in the top level -- sixteen of them just to get from the root down to the
+// leaf around its own origin, and every ancestor's box has to be tested on the way -- for 1.26 instances entered.  A grid
+// finds the cell of a point in O(1): the ray is clipped to the grid's box, starts in the cell of its first point there and
+// steps from cell to cell (3D DDA), testing the world boxes of the instances listed in each cell; it stops when the closest
+// hit so far lies before the end of the current cell.
+//  * An instance overlapping several cells is listed in all of them and entered once: in the cell that holds the point
+//    where the ray enters its box (t_entry >= t_in - slack; before that cell the ray is not in the box, in a later cell
+//    the instance has been entered already).  With the slack an instance may be entered twice (rarely; the closest hit
+//    does not care), never not at all: the boxes of the entries and the cells an instance is listed in are grown by
+//    grid_slack, far more than the rounding of the cell walk can misplace a point.
+//  * Order and termination are by t along the ray, so S5 (closest hit, ties to the lowest ids) holds as in any other walk:
+//    the walk ends only when best t < the current cell's exit t - slack, and an instance holding a hit at best t has its
+//    entry point at or before best t, i.e. in a cell already visited.
+// The bottom level is walked as in trace_run (same node_step, same triangle loop); the stack holds bottom-level entries only
+// and its sentinel is the "back to the top level" marker, so an instance entry pushes nothing.
+struct GridWalk {
+    u32 cell;              // x | y << 10 | z << 20
+    float tnx, tny, tnz;   // t at which the ray leaves the current cell through its next x / y / z plane
+    float t_in;            // t at which it entered the current cell
+    float t_end;           // t at which it leaves the grid's box
+    u32 e, e_end;          // entries of the current cell still to test
+    float idx, idy, idz;   // 1 / d, magnitude within [1e-30, 1e18] (box_rcp)
+    float slack_t;         // grid_slack as a distance along the ray
+};
+
+RT_DEV u32 grid_cell_index(const SceneView& sc, u32 cell) {
+    const u32 x = cell & 1023u, y = (cell >> 10) & 1023u, z = cell >> 20;
+    const u32 i = (z * sc.grid_res[1] + y) * sc.grid_res[0] + x;
+    return i < sc.grid_cells ? i : sc.grid_cells - 1u; // (cannot be out of range; a wrong cell costs time, a wrong address the GPU)
+}
+RT_DEV void grid_load_cell(const SceneView& sc, GridWalk& g) {
+    const RT_GLOBAL u32* st = (const RT_GLOBAL u32*) sc.grid_start + grid_cell_index(sc, g.cell);
+    const u32 a = st[0], b = st[1];
+    g.e = a < sc.grid_n_entries ? a : sc.grid_n_entries;
+    g.e_end = b < sc.grid_n_entries ? b : sc.grid_n_entries;
+}
+// returns false when the ray misses the grid's box within [tmin, best_t]
+RT_DEV bool grid_begin(const SceneView& sc, f3 o, f3 d, float tmin, float best_t, GridWalk& g) {
+    g.idx = box_rcp(d.x); g.idy = box_rcp(d.y); g.idz = box_rcp(d.z);
+    const float hx = sc.grid_lo[0] + (float) sc.grid_res[0] * sc.grid_cell[0], hy = sc.grid_lo[1] + (float) sc.grid_res[1] * sc.grid_cell[1], hz = sc.grid_lo[2] + (float) sc.grid_res[2] * sc.grid_cell[2];
+    const float ax = (sc.grid_lo[0] - o.x) * g.idx, bx = (hx - o.x) * g.idx;
+    const float ay = (sc.grid_lo[1] - o.y) * g.idy, by = (hy - o.y) * g.idy;
+    const float az = (sc.grid_lo[2] - o.z) * g.idz, bz = (hz - o.z) * g.idz;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float idmin = fminf(fminf(fabsf(g.idx), fabsf(g.idy)), fabsf(g.idz));
+    g.slack_t = sc.grid_slack * idmin;
+    const float t0 = fmaxf(tn, tmin);
+    g.t_end = tf + g.slack_t;
+    g.t_in = t0;
+    g.e = 0; g.e_end = 0;
+    if (!(t0 <= fminf(g.t_end, best_t))) return false; // (NaN: false)
+    // the cell of the ray's first point in the box, clamped into the grid
+    const f3 p = mk3(__builtin_fmaf(d.x, t0, o.x), __builtin_fmaf(d.y, t0, o.y), __builtin_fmaf(d.z, t0, o.z));
+    int c[3]; float tnext[3];
+    const float pk[3] = { p.x, p.y, p.z }, ok[3] = { o.x, o.y, o.z }, idk[3] = { g.idx, g.idy, g.idz };
+    for (int k = 0; k < 3; k++) {
+        const float q = (pk[k] - sc.grid_lo[k]) * sc.grid_inv_cell[k];
+        const float qc = fminf(fmaxf(q, 0.0f), (float) (sc.grid_res[k] - 1u)); // (NaN -> 0)
+        c[k] = (int) qc;
+        const float plane = sc.grid_lo[k] + (float) (c[k] + (idk[k] >= 0.0f ? 1 : 0)) * sc.grid_cell[k];
+        tnext[k] = (plane - ok[k]) * idk[k];
+    }
+    g.cell = (u32) c[0] | ((u32) c[1] << 10) | ((u32) c[2] << 20);
+    g.tnx = tnext[0]; g.tny = tnext[1]; g.tnz = tnext[2];
+    grid_load_cell(sc, g);
+    return true;
+}
+// Leaves the current cell; false when the walk is over (the closest hit lies before the cell's end, or the ray leaves the grid).
+RT_DEV bool grid_next_cell(const SceneView& sc, float best_t, GridWalk& g) {
+    const float t_out = fminf(fminf(g.tnx, g.tny), g.tnz);
+    if (!(t_out - g.slack_t <= best_t) || !(t_out <= g.t_end)) return false;
+    // the axis whose plane comes first (ties: x before y before z; the cells a tie skips are a slack away and listed alike)
+    const bool sx = g.tnx <= g.tny && g.tnx <= g.tnz, sy = !sx && g.tny <= g.tnz;
+    const float id = sx ? g.idx : sy ? g.idy : g.idz;
+    const int shift = sx ? 0 : sy ? 10 : 20;
+    const u32 res = sx ? sc.grid_res[0] : sy ? sc.grid_res[1] : sc.grid_res[2];
+    const float cs = sx ? sc.grid_cell[0] : sy ? sc.grid_cell[1] : sc.grid_cell[2];
+    const int ck = (int) ((g.cell >> shift) & 1023u) + (id >= 0.0f ? 1 : -1);
+    if (ck < 0 || ck >= (int) res) return false; // out of the grid
+    g.cell = (g.cell & ~(1023u << shift)) | ((u32) ck << shift);
+    const float dt = cs * fabsf(id);
+    if (sx) g.tnx += dt; else if (sy) g.tny += dt; else g.tnz += dt;
+    g.t_in = t_out;
+    grid_load_cell(sc, g);
+    return true;
+}
+// Tests entry g.e of the current cell (g.e < g.e_end) and moves past it; true: the ray has to enter instance `inst` now.
+RT_DEV bool grid_test_entry(const SceneView& sc, f3 o, float tmin, float best_t, GridWalk& g, int& inst) {
+    const RT_GLOBAL GridEntry* en = (const RT_GLOBAL GridEntry*) sc.grid_entries + g.e;
+    const Quad q0 = ldq(en, 0), q1 = ldq(en, 1);
+    g.e++;
+    const float ax = (q0.x - o.x) * g.idx, bx = (q1.x - o.x) * g.idx;
+    const float ay = (q0.y - o.y) * g.idy, by = (q1.y - o.y) * g.idy;
+    const float az = (q0.z - o.z) * g.idz, bz = (q1.z - o.z) * g.idz;
+    const float te = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), tmin);
+    const float tx = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), best_t);
+    inst = (int) as_u32(q0.w);
+    // the box is met within [tmin, closest hit so far] (it is grown by grid_slack: the comparison itself needs no more than
+    // its relative slack), and this is the cell in which the ray enters it
+    return te <= __builtin_fmaf(1.0e-5f, fabsf(te) + fabsf(tx), tx) && te >= g.t_in - g.slack_t;
+}
+
+template <class Stack, bool COUNT>
+RT_DEV void trace_run_grid(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, Stack& st, TraceState& S, TraverseCounters& cnt) {
+    st.lds[0] = RT_STACK_MARKER; st.sp = 0; // the sentinel of the bottom-level stack: "back to the top level"
+    if (sc.inl_inst >= 0 && S.cur != RT_TRAVERSAL_DONE) inlined_triangles_first<COUNT>(sc, o, d, tmin, sc.inl_inst, S.ch, cnt);
+    GridWalk g;
+    bool walking = S.cur != RT_TRAVERSAL_DONE && grid_begin(sc, o, d, tmin, S.ch.t, g);
+    S.cur = walking ? RT_STACK_MARKER : RT_TRAVERSAL_DONE;
+    S.bottom = false;
+    for (;;) {
+        // ---- bottom-level inner nodes ------------------------------------------------------------------------------
+        while (S.cur >= 0) S.cur = node_step<Stack, COUNT>(S.nodes, S.br, S.cur, tmin, S.ch.t, st, cnt);
+        if (S.cur == RT_TRAVERSAL_DONE) break;
+        if (S.cur == RT_STACK_MARKER) {
+            // ---- top level: the next instance to enter, or the end of the walk -----------------------------------------
+            int inst = -1;
+            for (;;) {
+                if (g.e >= g.e_end) { // (a cell may be empty: the lane steps again on the next trip)
+                    if (COUNT) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; } // a cell step counts as a node step
+                    if (!grid_next_cell(sc, S.ch.t, g)) { S.cur = RT_TRAVERSAL_DONE; break; }
+                }
+                if (g.e < g.e_end) {
+                    if (COUNT) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; } // and so does a box test
+                    if (grid_test_entry(sc, o, tmin, S.ch.t, g, inst)) break;
+                }
+            }
+            if (S.cur == RT_TRAVERSAL_DONE) break;
+            // ---- enter the instance ----------------------------------------------------------------------------------------
+            S.cur_inst = (u32) inst < sc.n_insts ? inst : 0;
+            if (COUNT) { cnt.insts++; if (first_active_lane()) cnt.inst_trips++; }
+            trace_bottom_level(sc, o, d, S);
+            S.cur = 0; st.sp = 0; // the stack is the marker alone again (the pop that returned it left sp at -1)
         } else {
             // ---- BLAS leaf: up to 8 triangles ------------------------------------------------------------------
             int v = ~S.cur;

@@ -410,7 +410,10 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
     // by registers, 19 per CU by their 8.25 KB of LDS, all of it stack, the side store in registers (LaneStack SIDE_REGS)
     // -- the node step without the clamps and overflow branches of the spilling stack (41 instead of 50 vector instructions)
     constexpr bool DEEP = !PERSISTENT && !SPILL && FLAT == 0 && WAVES_PER_SIMD == 5;
-    __shared__ int smem[(DEEP ? 33 : WAVES_PER_SIMD == 8 ? 20 : WAVES_PER_SIMD == 7 ? 22 : 26) * TRAVERSE_WAVE]; // 8 waves per SIMD = 32 per CU: 5 KB each of the 160 KB; 7: 28 per CU, 5.5 KB
+    // FLAT = 4: two-level scene with a grid top level (trace_run_grid): the stack holds bottom-level entries only, RT_GRID_STACK_ROWS rows
+    constexpr bool GRID = FLAT == 4;
+    static_assert(!GRID || (!PERSISTENT && !SPILL), "the grid walk keeps its stack in LDS");
+    __shared__ int smem[(GRID ? RT_GRID_STACK_ROWS : DEEP ? 33 : WAVES_PER_SIMD == 8 ? 20 : WAVES_PER_SIMD == 7 ? 22 : 26) * TRAVERSE_WAVE]; // 8 waves per SIMD = 32 per CU: 5 KB each of the 160 KB; 7: 28 per CU, 5.5 KB
     typedef LaneStack<SPILL, DEEP> Stack;
     TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
     u32 part = blockIdx.x % TASK_PARTS;
@@ -486,7 +489,12 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
             Stack st; st.lds = (RT_LDS int*) &smem[threadIdx.x]; st.spill = (RT_GLOBAL int*) (a.stack_spill + qi);
             st.spill_stride = a.n_paths; st.sp = 0;
             HitOut best;
-            if (FLAT > 0) {
+            if (GRID) {
+                TraceState S;
+                trace_begin(a.scene, o, d, a.tmax, S, false);
+                trace_run_grid<Stack, COUNT>(a.scene, o, d, a.tmin, a.tmax, st, S, cnt);
+                best = S.best;
+            } else if (FLAT > 0) {
                 trace_flat<(FLAT == 2 ? 2 : 1), Stack, COUNT, !PRIMARY, PRIMARY, FLAT == 3>(a.scene, o, d, a.tmin, a.tmax, st, best, cnt); // FLAT = 3: one instance in the tree, a small one tested first (SceneView::flat_inl_inst)
             } else {
                 TraceState S;
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(TRAVERSE_WAVE, WAVES_PER_SIMD) void k_traverse(Pass
                 rad = rad + r.emission * thr_prev;            // raytracing.hlsl:113
                 fused_sample_done(a, path, rad, sample_index, rng);
             } else {
-            const bool packed = FLAT > 0 || a.scene.flat_instances != 0u; // uniform
+            const bool packed = (FLAT > 0 && !GRID) || a.scene.flat_instances != 0u; // uniform
             int id = best.inst;
             if (packed) id = best.inst < 0 ? -1 : (best.inst << 30) | best.tri;
             ((float4*) a.hits.t)[qi] = make_float4(best.t, best.u, best.v, __int_as_float(id));
@@ -1639,6 +1647,15 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
             else if (two) hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 2>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
             else if (a.flat_waves8) hipLaunchKernelGGL((k_traverse<false, 8, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
             else hipLaunchKernelGGL((k_traverse<false, 6, false, false, false, 1>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+        }
+    } else if (a.scene.grid_cells != 0u && a.scene.flat_instances == 0u) {
+        // two-level scene with a grid top level (the host has checked that the bottom-level stacks fit RT_GRID_STACK_ROWS)
+        if (primary) {
+            if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true, false, false, 4>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+            else hipLaunchKernelGGL((k_traverse<false, 5, true, false, false, 4>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+        } else {
+            if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, false, false, false, 4>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
+            else hipLaunchKernelGGL((k_traverse<false, 5, false, false, false, 4>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);
         }
     } else if (primary) {
         if (count_traversal) hipLaunchKernelGGL((k_traverse<true, 1, true, false, true>), grid, block, 0, s, a, in_queue, sample_index, n_tasks, tail);

@@ -123,6 +123,31 @@ def test_pooled_and_per_lane_traversal_agree_with_the_oracle(oracle_mod, monkeyp
     _check_scene(scenes.bunny_field(128, 72, spp=1, bounces=2, grid=8, count=50), oracle_mod, brute_force=False)
 
 
+@pytest.mark.parametrize("grid", ["0", "2"])
+def test_grid_and_tree_top_levels_agree_with_the_oracle(oracle_mod, monkeypatch, grid):
+    """two-level scenes walk their top level as a tree (RT_TLAS_GRID=0) or as a uniform grid over the instances' world boxes
+    (2: wherever the bottom-level stacks allow; 1, the default, only where the instances suit it): the closest hit does not
+    depend on the order of the walk (S5), so both give the oracle's ids, t, u, v and RNG streams bit for bit.  Instances of
+    one size on a lattice, with and without the inlined floor; 1,500 small cubes of unequal sizes scattered in a volume
+    (three grid axes, cells with many entries, instances spanning several cells), against the brute-force oracle."""
+    monkeypatch.setenv("RT_TLAS_GRID", grid)       # read at rt_create
+    from raytracer_amd import api, host
+    rt = api.Raytracer(0)
+    sc = scenes.bunny_field(96, 54, spp=2, bounces=2, grid=8, count=40)
+    sc.setup(rt)
+    assert (rt.get_stats()["tlas_grid_cells"] > 0) == (grid == "2")
+    rt.close()
+    _check_scene(scenes.bunny_field(96, 54, spp=2, bounces=2, grid=8, count=40), oracle_mod, brute_force=False)
+    _check_scene(scenes.bunny_field(160, 90, spp=1, bounces=3, grid=20, count=300), oracle_mod, frames=2, brute_force=False)
+    s = scenes.debug_cube(96, 96, spp=1, bounces=2)
+    rs = np.random.RandomState(11)
+    s.instances = [(host.affine_transform(float(rs.uniform(0.02, 0.06)), float(rs.uniform(0, 6.28)),
+                                          tuple(rs.uniform(-0.7, 0.7, 3))), 0) for _ in range(1500)] + [s.instances[1]]
+    _check_scene(s, oracle_mod, frames=1, brute_force=True)
+    monkeypatch.setenv("RT_INLINE", "0")
+    _check_scene(scenes.bunny_field(128, 72, spp=1, bounces=2, grid=8, count=50), oracle_mod, brute_force=False)
+
+
 @pytest.mark.parametrize("builder", ["0", "1", "2", "3", "4"])
 def test_every_bvh_builder_gives_the_same_hits(oracle_mod, monkeypatch, builder):
     """the closest hit does not depend on the tree (S5): Karras LBVH (0), PLOC (1), binned SAH (2), the
