@@ -149,6 +149,10 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a one-GPU box: every rank uses GPU 0 and the collectives go through gloo (checks the "
                          "multi-rank code path; the numbers mean nothing)")
+    ap.add_argument("--with-collectives", action="store_true",
+                    help="N = 1: initialise the process group (RCCL unless --rehearse) and run the exchange step anyway, as a "
+                         "one-rank job: exercises the backend calls of the N > 1 path on a one-GPU box (needs the torch.distributed "
+                         "environment: launch through torch.distributed.run --nproc-per-node 1)")
     ap.add_argument("--dump-accumulator", default=None, metavar="FILE.npy",
                     help="rank 0 saves the float accumulator as it stands when the timed region ends (after the reduce): "
                          "lets a test compare the multi-rank image with the one-process image")
@@ -169,7 +173,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.with_collectives:
         import torch.distributed as dist
         if args.rehearse:
             dist.init_process_group("gloo")
@@ -183,10 +187,10 @@ def main():
         label += " [hierarchical gather, limit %g sr]" % args.hg
     rt = api.Raytracer(local_rank)
     points = scene.setup(rt)
-    tile = world > 1 and args.split == "tile"
+    tile = dist is not None and args.split == "tile"
     if tile:
         rt.set_tile_split(rank, world)
-    elif world > 1 and points:
+    elif dist is not None and points:
         distributed.require_no_sample_points(rt)   # payloads accumulate frame by frame: such scenes shard by tiles
     acc_ptr, acc_bytes = rt.accumulator_device_ptr()
     acc = torch.as_tensor(_DevBuf(acc_ptr, acc_bytes // 4), device=torch.device("cuda", local_rank))
@@ -464,8 +468,8 @@ def main():
                        "frames_in_flight": out_frames_in_flight(args)},
             "primary_Mrays_s": primary,        # bounce-0 launches alone (coherent), from their launch durations
             "secondary_Mrays_s": secondary,    # queued launches alone (scattered / sample-point rays: incoherent)
-            "reduce_ms": reduce_ms if world > 1 else None,   # the one exchange step, part of the timed job (rank 0's view)
-            "exchange": None if world == 1 else {"kind": "gather of owned tiles" if tile else "reduce(sum) of the accumulator",
+            "reduce_ms": reduce_ms if dist is not None else None,   # the one exchange step, part of the timed job (rank 0's view)
+            "exchange": None if dist is None else {"kind": "gather of owned tiles" if tile else "reduce(sum) of the accumulator",
                                                  "bytes_per_rank": exchange_bytes,
                                                  # one exchange per job of timed_blocks x steps frames: a block carries its share
                                                  "per_job_of_frames": n_blocks * args.steps, "ms_charged_per_block": reduce_ms / n_blocks},

@@ -267,3 +267,29 @@ def test_the_scale_run_commands_at_baseline_size(workload, split, size, tmp_path
         assert rec["exchange"]["bytes_per_rank"] == (tiles + 1) // 2 * 1024 * 16 < 0.51 * frame_bytes   # half of the tiles, not the frame
     else:
         assert rec["scaling"] == "weak" and rec["exchange"]["bytes_per_rank"] == frame_bytes
+
+
+@pytest.mark.parametrize("workload,split", [("c2", "sample"), ("c4", "tile")])
+def test_the_rccl_calls_of_the_multi_gpu_path_as_a_one_rank_job(workload, split, tmp_path):
+    """A one-GPU box cannot hold two RCCL ranks (one rank per device), so the backend calls of the N > 1 path -- process group
+    on the "nccl" backend with a device id, reduce(sum) of the product's accumulator through its zero-copy view, gather of
+    packed tiles, the MAX / SUM all-reduces of the timing, the barriers -- are run here as a job of ONE rank
+    (bench.py --with-collectives): same calls, same tensors, a communicator of size 1.  The image must be the plain
+    one-process image bit for bit (a reduce or a gather over one rank changes nothing)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, extra in (("plain", []), ("rccl", ["--with-collectives", "--split", split])):
+        dump = str(tmp_path / (tag + ".npy"))
+        base = [os.path.join(root, "bench.py"), "--gpus", "1", "--workload", workload, "--width", "320", "--height", "180", "--steps", "3",
+                "--warmup", "1", "--no-cpu", "--no-alone", "--dump-accumulator", dump] + extra
+        cmd = [sys.executable] + base if tag == "plain" else \
+              [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(29800 + os.getpid() % 90)] + base
+        r = subprocess.run(cmd, cwd=root, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = (json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]), np.load(dump))
+    rec, img = out["rccl"]
+    assert rec["n_gpus"] == 1 and rec["reduce_ms"] is not None and rec["exchange"]["kind"].startswith("gather" if split == "tile" else "reduce")
+    assert rec["config"]["parallelism"].startswith("tile split" if split == "tile" else "sample-set split") or rec["n_gpus"] == 1
+    assert np.array_equal(img.view(np.uint32), out["plain"][1].view(np.uint32))
