@@ -148,6 +148,21 @@ def test_grid_and_tree_top_levels_agree_with_the_oracle(oracle_mod, monkeypatch,
     _check_scene(scenes.bunny_field(128, 72, spp=1, bounces=2, grid=8, count=50), oracle_mod, brute_force=False)
 
 
+def test_grid_top_level_chosen_by_itself_for_a_field_of_instances(oracle_mod, monkeypatch):
+    """RT_TLAS_GRID=1: the library decides -- 4,500 meshes on a lattice get the grid, 300 do not (too few to pay), and the
+    Cornell box with its room-sized walls never does (a flat scene); hits as the oracle's either way"""
+    monkeypatch.setenv("RT_TLAS_GRID", "1")
+    from raytracer_amd import api
+    for sc, want in ((scenes.bunny_field(160, 90, spp=1, bounces=2, grid=70, count=4500), True),
+                     (scenes.bunny_field(96, 54, spp=1, bounces=2, grid=20, count=300), False),
+                     (scenes.cornell(64, 36, spp=1, bounces=2), False)):
+        rt = api.Raytracer(0)
+        sc.setup(rt)
+        assert (rt.get_stats()["tlas_grid_cells"] > 0) == want
+        rt.close()
+    _check_scene(scenes.bunny_field(160, 90, spp=1, bounces=2, grid=70, count=4500), oracle_mod, frames=1, brute_force=False)
+
+
 @pytest.mark.parametrize("builder", ["0", "1", "2", "3", "4"])
 def test_every_bvh_builder_gives_the_same_hits(oracle_mod, monkeypatch, builder):
     """the closest hit does not depend on the tree (S5): Karras LBVH (0), PLOC (1), binned SAH (2), the

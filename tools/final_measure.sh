@@ -11,7 +11,8 @@ case $stage in
 pmc)
   bash tools/pmc_passes.sh c2 --steps 40 --warmup 5 && bash tools/pmc_passes.sh c3 --workload c3 --steps 3 --warmup 1 &&
   bash tools/pmc_passes.sh c4 --workload c4 --steps 3 --warmup 1 && bash tools/pmc_passes.sh c5 --workload c5 --steps 16 --warmup 2 &&
-  bash tools/pmc_passes.sh c5_3840x2160 --workload c5 --width 3840 --height 2160 --steps 16 --warmup 2 || exit 1 ;;
+  bash tools/pmc_passes.sh c5_3840x2160 --workload c5 --width 3840 --height 2160 --steps 16 --warmup 2 &&
+  bash tools/pmc_passes.sh c3t --workload c3t --steps 40 --warmup 5 || exit 1 ;;
 bench)
   run() { name=$1; shift; timeout -k 10 400 python3 bench.py "$@" > gpurun_out/${tag}_$name.json 2> gpurun_out/${tag}_$name.err || { echo "$name failed"; tail -5 gpurun_out/${tag}_$name.err; exit 1; }; echo "$name done"; }
   run c2 ; run c2_driver --steps 20 --warmup 5 --no-cpu ; run c3 --workload c3 --steps 10 ; run c4 --workload c4 --steps 20
