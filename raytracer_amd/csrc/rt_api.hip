@@ -105,6 +105,12 @@ struct rt_ctx {
     // events per lane, made with the lane (ensure_gather_side); RT_GATHER_SIDE=1 -- measured, not kept (profiles/r03_ab_gather_side.txt): default in stream order
     int gather_side = 0; hipStream_t gather_stream[2] = { nullptr, nullptr }; hipEvent_t gather_ev[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };
     int cur_lane = 0; bool gather_pending = false;
+    // batched gather (run_pass; RT_GATHER_BATCH=0 switches it off, RT_GATHER_BATCH_MB bounds a lane's buffers): the gather items
+    // of a frame's shade launches are kept, row after row, and evaluated by one launch per frame (or per `rows` shade launches)
+    // instead of one small launch per bounce -- per lane: nine arrays of rows x n_paths items, the rows' per-segment counts, the
+    // numbering of the items (+ the launch's block counter)
+    struct BatchGather { float* d_arena = nullptr; u32* d_counts = nullptr; u32* d_off = nullptr; u32 rows = 0, stride = 0, cols_cap = 0; };
+    BatchGather bg[2]; int gather_batch = 1; size_t gather_batch_mb = 3072; bool no_alloc_call = false; int gather_groups = 2, gather_block = 256; /* RT_GATHER_GROUPS, RT_GATHER_BLOCK: workgroups per CU of the batched launch, threads of each */
     int fuse_tail = 1; // RT_FUSE_TAIL: the last bounce's traversal kernel of the fused camera pass shades its hits itself
     int fuse_primary = 1; // RT_FUSE_PRIMARY: bounce 0 of the fused camera pass as one kernel in flat one-instance scenes (k_shade<.., TRACE>)
     int wave_major = 1; // RT_WAVE_MAJOR
@@ -413,7 +419,7 @@ int timed_primary_fused(rt_ctx* c, const PassArgs& a, u32 sample_index) {
     return rc;
 }
 
-int timed_gather(rt_ctx* c, const PassArgs& a, hipStream_t stream) {
+int timed_gather(rt_ctx* c, const PassArgs& a, hipStream_t stream, bool batched = false) {
     bool timing = timing_now(c);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) {
@@ -421,7 +427,7 @@ int timed_gather(rt_ctx* c, const PassArgs& a, hipStream_t stream) {
         RT_HIP(hipEventRecord(e0, stream));
         c->gather_launches_timed++;
     }
-    int rc = launch_gather(stream, a);
+    int rc = batched ? launch_gather_batched(stream, a) : launch_gather(stream, a);
     if (timing) { RT_HIP(hipEventRecord(e1, stream)); c->timed_gather.emplace_back(e0, e1); }
     c->gather_launches++;
     return rc;
@@ -481,6 +487,30 @@ int drain_timers(rt_ctx* c) {
     return RT_OK;
 }
 
+// Buffers of the batched gather for the frame about to run on lane `lane` (c->stream is that lane's stream): as many rows as
+// the frame has gathering shade launches, as far as the budget goes.  *out = nullptr: this frame gathers launch by launch
+// (fewer than two rows, the hierarchical gather, RT_GATHER_BATCH=0, rt_dispatch_rays_static -- which must not allocate).
+int ensure_batch_gather(rt_ctx* c, int lane, rt_ctx::BatchGather** out) {
+    *out = nullptr;
+    if (!c->gather_batch || c->no_alloc_call || c->g.translucent_emission_bounces < 0 || c->n_paths == 0) return RT_OK;
+    const uint64_t per_sample = (uint64_t) std::min<int64_t>(c->g.translucent_emission_bounces, c->g.bounces_per_sample) + 1u;
+    const uint64_t want = per_sample * c->g.samples_per_pixel;
+    const uint64_t row_bytes = (uint64_t) 9 * 4 * c->n_paths;
+    const uint64_t rows = std::min<uint64_t>(std::min<uint64_t>(want, (uint64_t) c->gather_batch_mb * (1ull << 20) / row_bytes), (uint64_t) 0xffffffffu / c->n_paths);
+    if (rows < 2) return RT_OK;
+    rt_ctx::BatchGather& b = c->bg[lane];
+    if (b.rows < rows || b.stride != c->n_paths || b.cols_cap != c->n_segments_cap) {
+        RT_HIP(hipStreamSynchronize(c->stream)); // the lane's last frame may still read the old buffers
+        dev_free(b.d_arena); dev_free(b.d_counts); dev_free(b.d_off); b.rows = 0;
+        RT_HIP(hipMalloc(&b.d_arena, rows * row_bytes));
+        RT_HIP(hipMalloc(&b.d_counts, sizeof(u32) * rows * c->n_segments_cap));
+        RT_HIP(hipMalloc(&b.d_off, sizeof(u32) * (rows * c->n_segments_cap + 2)));
+        b.rows = (u32) rows; b.stride = c->n_paths; b.cols_cap = c->n_segments_cap;
+    }
+    *out = &b;
+    return RT_OK;
+}
+
 // the loop of trace_path_sample (raytracing.hlsl:101-120) over all paths of a pass, wavefront style
 int run_pass(rt_ctx* c, bool probe) {
     PassArgs a; fill_pass_args(c, a, probe);
@@ -502,12 +532,44 @@ int run_pass(rt_ctx* c, bool probe) {
     bool fused = !probe && !gather;
     a.defer_resolve = (c->defer_resolve && fused) ? 1u : 0u;
     a.lazy_render_target = c->defer_resolve ? 1u : 0u;
+    // Batched gather: the shade launches that queue gather items write them to a row of their own; one k_gather launch evaluates
+    // the rows of the whole frame (or of as many launches as there are rows) and k_gather_apply adds the terms to the paths'
+    // radiance in the order of the rows.  The terms are the ones the launch-by-launch gather adds; a path's radiance sums them
+    // after, instead of between, the emission of its later bounces (radiance only: the 1e-4 contract; measured 1e-7).
+    rt_ctx::BatchGather* bg = nullptr;
+    if (gather && !a.hg.enabled) { int brc = ensure_batch_gather(c, c->cur_lane, &bg); if (brc) return brc; }
+    PassArgs ab = a; u32 bg_row = 0;
+    auto gq_row = [&](PassArgs& x, u32 row) { // the gather queue of x: row `row` of the batch buffers
+        const size_t rs = (size_t) bg->rows * bg->stride; float* p = bg->d_arena + (size_t) row * bg->stride;
+        x.gq.path = (u32*) p; x.gq.hx = p + rs; x.gq.hy = p + 2 * rs; x.gq.hz = p + 3 * rs; x.gq.tf = p + 4 * rs;
+        x.gq.kx = p + 5 * rs; x.gq.ky = p + 6 * rs; x.gq.kz = p + 7 * rs; x.gq.ti = (int*) (p + 8 * rs);
+        x.gseg_count = bg->d_counts + (size_t) row * a.n_segments;
+    };
+    auto flush_rows = [&]() -> int {
+        if (!bg || !bg_row) return RT_OK;
+        ab.bg_rows = bg_row; bg_row = 0;
+        return timed_gather(c, ab, c->stream, true);
+    };
+    if (bg) {
+        gq_row(ab, 0);
+        ab.bg_cols = a.n_segments; ab.bg_stride = bg->stride; ab.bg_counts = bg->d_counts; ab.goff = bg->d_off;
+        ab.bg_block = (u32) c->gather_block; ab.bg_groups = (u32) c->gather_groups * c->cu_count; // two 256-thread workgroups per CU: 2 waves per SIMD.  The LDS (35 KB each) would allow four, and alone on the GPU the launch is fastest with four; beside the other frame's short, latency-bound launches two leave them the room they need (C4 8.55 against 8.1 Grays/s, profiles/r03_ab_gather_batch.txt)
+    }
     for (u32 s = 0; s < c->g.samples_per_pixel; s++) {
         int rc = RT_OK;
         if (probe) { rc = launch_probe_raygen(c->stream, a, s); if (rc) return rc; }
         for (u32 b = 0; b <= c->g.bounces_per_sample; b++) {
             bool primary = !probe && b == 0;
             if (primary && fused && a.fuse_primary) { rc = timed_primary_fused(c, a, s); if (rc) return rc; } // walk + shade in one kernel
+            else if (gather && bg) {
+                rc = timed_traverse(c, a, b & 1u, primary, s); if (rc) return rc;
+                if ((int) b <= c->g.translucent_emission_bounces) { // this shade queues gather items: into the next row
+                    PassArgs as = a; gq_row(as, bg_row);
+                    rc = launch_shade(c->stream, as, b & 1u, b, s, primary, fused); if (rc) return rc;
+                    if (++bg_row == bg->rows) { rc = flush_rows(); if (rc) return rc; }
+                } else { rc = launch_shade(c->stream, a, b & 1u, b, s, primary, fused); if (rc) return rc; }
+                continue;
+            }
             else if (gather) { // (the gather of the bounce before may still run on its side stream: the traversal does not care, the shade waits)
                 rc = timed_traverse(c, a, b & 1u, primary, s); if (rc) return rc;
                 rc = gather_join(c); if (rc) return rc;
@@ -524,6 +586,7 @@ int run_pass(rt_ctx* c, bool probe) {
         }
     }
     { int jrc = gather_join(c); if (jrc) return jrc; } // (a sample whose last bounce gathers: nothing after it has waited yet)
+    { int frc = flush_rows(); if (frc) return frc; }
     if (probe) return launch_probe_resolve(c->stream, a);
     if (fused && !c->defer_resolve) return RT_OK;
     // pipelined frames: pixels are added to in frame order, by the frame's resolve kernel alone; all the tracing, shading
@@ -847,6 +910,10 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_GATHER_SIDE")) c->gather_side = atoi(v);
     if (const char* v = getenv("RT_POOL")) c->pool = atoi(v);
     if (const char* v = getenv("RT_GATHER_L1")) c->gather_l1 = atoi(v);
+    if (const char* v = getenv("RT_GATHER_BATCH")) c->gather_batch = atoi(v);
+    if (const char* v = getenv("RT_GATHER_BLOCK")) { const int n = atoi(v); if (n == 256 || n == 512 || n == 1024) c->gather_block = n; }
+    if (const char* v = getenv("RT_GATHER_GROUPS")) { const int n = atoi(v); if (n >= 1 && n <= 16) c->gather_groups = n; }
+    if (const char* v = getenv("RT_GATHER_BATCH_MB")) { const long mb = atol(v); if (mb > 0) c->gather_batch_mb = (size_t) mb; }
     if (const char* v = getenv("RT_XCD_BANDS")) c->xcd_bands = atoi(v);
     if (const char* v = getenv("RT_SORT_BOX")) c->sort_box = atoi(v);
     if (const char* v = getenv("RT_SORT_CHORD")) c->sort_chord_pct = (float) atof(v);
@@ -901,6 +968,7 @@ void rt_destroy(rt_ctx* c) {
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     (void) drain_timers(c);
     dev_free(c->alt.d_arena); dev_free(c->alt.d_seg_count);
+    for (auto& b : c->bg) { dev_free(b.d_arena); dev_free(b.d_counts); dev_free(b.d_off); }
     if (c->alt_stream) (void) hipStreamDestroy(c->alt_stream);
     for (int l = 0; l < 2; l++) { if (c->gather_stream[l]) { (void) hipStreamSynchronize(c->gather_stream[l]); (void) hipStreamDestroy(c->gather_stream[l]); }
                                   for (int k = 0; k < 2; k++) if (c->gather_ev[l][k]) (void) hipEventDestroy(c->gather_ev[l][k]); }
@@ -1521,7 +1589,9 @@ int rt_dispatch_rays_static(rt_ctx* c) {
     // the array keeps the last call's contents: the segment fills start at zero like freshly allocated ones
     hipError_t e = hipMemsetAsync(base, 0, RT_STATIC_SEG_BYTES, c->stream);
     if (e != hipSuccess) { set_error("rt_dispatch_rays_static: hipMemsetAsync failed: %s", hipGetErrorString(e)); rc = RT_ERR_DEVICE; }
+    c->no_alloc_call = true; // (the batched gather would allocate its rows)
     if (rc == RT_OK) rc = dispatch_serial(c);
+    c->no_alloc_call = false;
     exchange();
     c->n_paths = own_paths; c->n_segments_cap = own_cap;
     return rc;

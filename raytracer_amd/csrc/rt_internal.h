@@ -176,6 +176,12 @@ struct PassArgs {
     u32* gseg_count;             // gather items per segment
     u32* goff;                   // [n_segments + 1] exclusive scan of gseg_count (k_gather_offsets)
     const float4* sp_pay;        // payloads of sp_read in the Morton order of the points (k_sort_payload, k_gather)
+    // batched gather (rt_api.hip run_pass, RT_GATHER_BATCH): the gather items of up to bg_rows shade launches of a frame are kept --
+    // row r of the nine gather-queue arrays starts at slot r * bg_stride, its per-segment counts at bg_counts[r * bg_cols] -- and
+    // evaluated by ONE k_gather launch (goff then numbers the items of all rows: bg_rows * bg_cols + 1 entries, then the block
+    // counter of that launch); 0 = every shade launch is followed by its own gather launch
+    u32 bg_rows, bg_cols, bg_stride, bg_groups, bg_block; // bg_groups workgroups of bg_block threads
+    const u32* bg_counts;
     int* stack_spill;            // [48][n_paths] overflow of the per-lane traversal stack
     DeviceStats* stats;
     RtHit* capture;              // [(bounces+1) * width*height] or null
@@ -200,6 +206,8 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
 // fused: finished camera paths resolve their pixel in the shade kernel (no launch_camera_resolve afterwards)
 int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index, bool primary, bool fused);
 int launch_gather(hipStream_t s, const PassArgs& a);
+// batched gather: one launch for the items of a.bg_rows shade launches (a.gq = row 0), then their terms added to the paths' radiance row by row
+int launch_gather_batched(hipStream_t s, const PassArgs& a);
 int launch_gather_delta(hipStream_t s, const float* table, int n, float factor, float4* delta);
 int launch_sort_payload(hipStream_t s, const RtSamplePoint* src, const u32* order, const u32* slice_of, const rtd::TranslucentSlice* slices, u32 n, float4* pay);
 int launch_hg_sums(hipStream_t s, const PassArgs& a, u32 n_slices); // refresh HgView::pay / sums from sp_read

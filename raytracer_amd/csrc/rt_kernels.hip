@@ -1208,50 +1208,73 @@ RT_DEV void tab_fill_lds(float4* tab, const float* table, int n, float factor) {
 __global__ __launch_bounds__(SEG) void k_gather_offsets(PassArgs a) {
     __shared__ u32 s_wave[SEG / 64];
     __shared__ u32 s_carry;
+    // batched gather: the counts of all rows (shade launches) kept for this launch, row after row
+    const u32 n = a.bg_rows ? a.bg_rows * a.bg_cols : a.n_segments;
+    const u32* cnt = a.bg_rows ? a.bg_counts : a.gseg_count;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    for (u32 b0 = 0; b0 < a.n_segments; b0 += SEG) {
+    for (u32 b0 = 0; b0 < n; b0 += SEG) {
         const u32 i = b0 + threadIdx.x;
-        const u32 v = i < a.n_segments ? a.gseg_count[i] : 0u;
+        const u32 v = i < n ? cnt[i] : 0u;
         u32 inc = v;
         for (int off = 1; off < 64; off <<= 1) { u32 t = __shfl_up(inc, off); if ((int) lane >= off) inc += t; }
         if (lane == 63) s_wave[wave] = inc;
         __syncthreads();
         u32 base = s_carry, total = 0;
         for (u32 w = 0; w < SEG / 64; w++) { u32 c = s_wave[w]; if (w < wave) base += c; total += c; }
-        if (i < a.n_segments) a.goff[i] = base + inc - v;
+        if (i < n) a.goff[i] = base + inc - v;
         __syncthreads();
         if (threadIdx.x == 0) s_carry += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.goff[a.n_segments] = s_carry;
+    if (threadIdx.x == 0) { a.goff[n] = s_carry; if (a.bg_rows) a.goff[n + 1u] = 0u; /* the block counter of the batched launch */ }
 }
 
 // MODE: 0 = dipole, 1 = tabulated profile in LDS, 2 = tabulated profile too long for LDS (read from global memory);
 // a template parameter so that the unrolled loop body is straight-line code the scheduler can interleave
-template <int MODE>
-__global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
+template <int MODE, int BLOCK = 256>
+__global__ __launch_bounds__(BLOCK) void k_gather(PassArgs a) {
     __shared__ GatherPoint s_pts[MODE == 0 ? GATHER_TILE : 1];
     __shared__ float4 s_tab[(MODE == 1 || MODE == 3) ? GATHER_TABLE_MAX + 4 : 1];
     __shared__ int s_next;
-    const u32 n_items = a.goff[a.n_segments];
-    if (blockIdx.x * GATHER_BLOCK >= n_items) return; // uniform
-    const u32 j = blockIdx.x * GATHER_BLOCK + threadIdx.x;
+    __shared__ u32 s_blk;
+    // Batched launch (a.bg_rows > 0: the items of several shade launches, launch_gather_batched): goff numbers the items of all
+    // rows, the grid is sized to the machine and its workgroups take blocks of 256 items from a counter until none is left --
+    // the table is filled once per workgroup, and a launch holds enough waves to keep the SIMDs busy (one shade launch of C4
+    // leaves ~115,000 items: 1.8 waves per SIMD, each a chain of 759 dependent point evaluations).
+    const u32 n_entries = a.bg_rows ? a.bg_rows * a.bg_cols : a.n_segments;
+    const u32 n_items = a.goff[n_entries];
+    if (!a.bg_rows && blockIdx.x * BLOCK >= n_items) return; // uniform
+    const GatherQueue& g = a.gq;
+    const float scale = a.g.translucent_bssrdf_scale;
+    if (MODE == 1 || MODE == 3)
+        tab_fill_lds<BLOCK>(s_tab, a.bssrdf_table, a.bssrdf_texels, a.fudge / (scale * scale)); // (the first barrier below covers it)
+    u32 pairs = 0;
+    u32 blk = blockIdx.x;
+    for (;;) {
+    if (a.bg_rows) { // uniform
+        __syncthreads();
+        if (threadIdx.x == 0) s_blk = atomicAdd(&a.goff[n_entries + 1u], 1u);
+        __syncthreads();
+        blk = s_blk;
+        if (blk * BLOCK >= n_items) break; // uniform
+    }
+    const u32 j = blk * BLOCK + threadIdx.x;
     bool active = j < n_items;
-    u32 i;
+    size_t i;
     {   // item j of the numbering -> its segment (last s with goff[s] <= j) -> its queue slot
         const u32 jj = active ? j : n_items - 1u;
-        u32 lo = 0, hi = a.n_segments; // goff[lo] <= jj < goff[hi]
+        u32 lo = 0, hi = n_entries; // goff[lo] <= jj < goff[hi]
         while (hi - lo > 1u) { u32 mid = (lo + hi) >> 1; if (a.goff[mid] <= jj) lo = mid; else hi = mid; }
-        i = lo * SEG + (jj - a.goff[lo]);
+        const u32 row = a.bg_rows ? lo / a.bg_cols : 0u, col = lo - row * a.bg_cols;
+        i = (size_t) row * a.bg_stride + (size_t) col * SEG + (jj - a.goff[lo]);
     }
-    const GatherQueue& g = a.gq;
     if ((MODE == 1 || MODE == 3) && a.sort_box_on == 1u) {
         // The workgroup's items regrouped by the cell of the mesh's box their hit lies in: the hits of a wave then sit
         // together, and more of the far point groups below are far for the whole wave (the skip needs every lane to agree)
         __shared__ u32 s_key[66];
-        __shared__ u32 s_perm[GATHER_BLOCK];
+        __shared__ size_t s_perm[BLOCK];
         if (threadIdx.x < 66) s_key[threadIdx.x] = 0u;
         __syncthreads();
         u32 key = 64u; // inactive threads last
@@ -1283,9 +1306,6 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
     }
     const f3 hit = mk3(g.hx[i], g.hy[i], g.hz[i]);
     const int my_ti = active ? g.ti[i] : -1;
-    const float scale = a.g.translucent_bssrdf_scale;
-    if (MODE == 1 || MODE == 3)
-        tab_fill_lds<GATHER_BLOCK>(s_tab, a.bssrdf_table, a.bssrdf_texels, a.fudge / (scale * scale));
     // radiance-only arithmetic (covered by the 1e-4 tolerance): fudge / scale^2 is folded into one
     // factor, and the dipole uses the hardware sqrt / rcp / exp2.  The table coordinate radius / scale stays (all but)
     // correctly rounded -- near the end of the profile's support the texels are ~1e-7 and an ulp of the coordinate is a
@@ -1300,7 +1320,6 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
     const bool grey = a.g.translucent_scattering[0] == a.g.translucent_scattering[1] && a.g.translucent_scattering[0] == a.g.translucent_scattering[2] &&
                       a.g.translucent_absorption[0] == a.g.translucent_absorption[1] && a.g.translucent_absorption[0] == a.g.translucent_absorption[2];
     f3 E = mk3(0.0f, 0.0f, 0.0f);
-    u32 pairs = 0;
     // translucent instances present in this workgroup, in increasing index order
     int cur = -1;
     for (;;) {
@@ -1320,7 +1339,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
             for (u32 k0 = 0; k0 < sl.count; k0 += GATHER_TILE) {
                 const u32 nk = sl.count - k0 < (u32) GATHER_TILE ? sl.count - k0 : (u32) GATHER_TILE;
                 __syncthreads(); // the previous tile is no longer read
-                for (u32 t = threadIdx.x; t < nk; t += GATHER_BLOCK) {
+                for (u32 t = threadIdx.x; t < nk; t += BLOCK) {
                     const RtSamplePoint sp = pts[k0 + t];
                     GatherPoint gp;
                     gp.px = sp.position[0]; gp.py = sp.position[1]; gp.pz = sp.position[2]; gp.pad0 = 0.0f;
@@ -1427,11 +1446,34 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(PassArgs a) {
         E = E / (float) (a.g.translucent_accumulator_count + 1u);                                       // :332
         f3 emission = E * g.tf[i] / (RT_TAU_F / 2.0f);                                                 // :347
         f3 k3 = mk3(g.kx[i], g.ky[i], g.kz[i]);
-        const u32 path = g.path[i];
-        a.ps.rad_x[path] += emission.x * k3.x; a.ps.rad_y[path] += emission.y * k3.y; a.ps.rad_z[path] += emission.z * k3.z;
+        if (a.bg_rows) { g.kx[i] = emission.x * k3.x; g.ky[i] = emission.y * k3.y; g.kz[i] = emission.z * k3.z; } // the item's term: added to its path by k_gather_apply, row by row
+        else {
+            const u32 path = g.path[i];
+            a.ps.rad_x[path] += emission.x * k3.x; a.ps.rad_y[path] += emission.y * k3.y; a.ps.rad_z[path] += emission.z * k3.z;
+        }
     }
-    pairs = wave_sum(active ? pairs : 0u);
+    if (!a.bg_rows) break;
+    } // the next block of items
+    pairs = wave_sum(pairs);
     if ((threadIdx.x & 63u) == 0 && pairs) atomicAdd(&a.stats->gather_pairs, (unsigned long long) pairs);
+}
+
+// Batched gather, last step: the terms k_gather left in the items (kx, ky, kz) are added to the radiance of their paths, row
+// by row -- the rows are the shade launches in the order they ran, so a path that met translucent surfaces at several bounces
+// (or, later in the frame, in several samples) gets its terms in that order, whichever workgroups evaluated them: the result
+// does not depend on the scheduling of the gather launch.  One workgroup per queue segment (the items of a segment's paths
+// sit in that segment of every row); a path has at most one item per row.
+__global__ __launch_bounds__(SEG) void k_gather_apply(PassArgs a) {
+    const GatherQueue& g = a.gq;
+    for (u32 r = 0; r < a.bg_rows; r++) {
+        const u32 cnt = a.bg_counts[r * a.bg_cols + blockIdx.x];
+        if (threadIdx.x < cnt) {
+            const size_t i = (size_t) r * a.bg_stride + (size_t) blockIdx.x * SEG + threadIdx.x;
+            const u32 path = g.path[i];
+            a.ps.rad_x[path] += g.kx[i]; a.ps.rad_y[path] += g.ky[i]; a.ps.rad_z[path] += g.kz[i];
+        }
+        __syncthreads(); // the next row may name the same paths
+    }
 }
 
 // payloads of the sample points in the Morton order of their positions (HgView::order), for k_gather's walk: run whenever
@@ -1708,6 +1750,24 @@ int launch_gather(hipStream_t s, const PassArgs& a) {
     else if (a.bssrdf_texels <= GATHER_TABLE_MAX && a.gather_delta) hipLaunchKernelGGL(k_gather<3>, grid, block, 0, s, a);
     else if (a.bssrdf_texels <= GATHER_TABLE_MAX) hipLaunchKernelGGL(k_gather<1>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(k_gather<2>, grid, block, 0, s, a);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+template <int BLOCK>
+static void launch_gather_batched_block(hipStream_t s, const PassArgs& a) {
+    dim3 grid(a.bg_groups), block(BLOCK);
+    if (a.g.translucent_bssrdf_scale == 0.0f) hipLaunchKernelGGL((k_gather<0, BLOCK>), grid, block, 0, s, a); // raytracing.hlsl:316-320
+    else if (a.bssrdf_texels <= GATHER_TABLE_MAX && a.gather_delta) hipLaunchKernelGGL((k_gather<3, BLOCK>), grid, block, 0, s, a);
+    else if (a.bssrdf_texels <= GATHER_TABLE_MAX) hipLaunchKernelGGL((k_gather<1, BLOCK>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_gather<2, BLOCK>), grid, block, 0, s, a);
+}
+int launch_gather_batched(hipStream_t s, const PassArgs& a) {
+    if (!a.bg_rows || !a.bg_cols || !a.bg_groups) return RT_OK;
+    hipLaunchKernelGGL(k_gather_offsets, dim3(1), dim3(SEG), 0, s, a);
+    if (a.bg_block == 1024u) launch_gather_batched_block<1024>(s, a);
+    else if (a.bg_block == 512u) launch_gather_batched_block<512>(s, a);
+    else launch_gather_batched_block<256>(s, a);
+    hipLaunchKernelGGL(k_gather_apply, dim3(a.bg_cols), dim3(SEG), 0, s, a);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
