@@ -156,3 +156,43 @@ def test_dipole_with_per_channel_coefficients(oracle_mod):
     _check_translucent(s, oracle_mod, frames=2)
     s.gather_mode = (True, 0.3)
     _check_translucent(s, oracle_mod, frames=1)
+
+
+# ---- batched gather (RT_GATHER_BATCH; rt_api.hip run_pass) --------------------------------------------
+def _render_c4(monkeypatch, env, frames=3, **scene_kw):
+    from raytracer_amd import api, distributed
+    for k in ("RT_GATHER_BATCH", "RT_GATHER_BATCH_MB", "RT_FRAMES_IN_FLIGHT", "RT_GATHER_GROUPS", "RT_GATHER_BLOCK"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)        # read at rt_create
+    s = scenes.cornell_bunny(160, 96, spp=3, bounces=3, sample_radius=0.04, **scene_kw)
+    rt = api.Raytracer(0)
+    try:
+        s.setup(rt)
+        for f in range(frames):
+            distributed.render_frame(rt, s.globals, f, 11)   # no capture flags: pipelined frames, the production path
+        return rt.read_accumulator(), rt.get_stats()
+    finally:
+        rt.close()
+
+
+@pytest.mark.parametrize("tabulated", [True, False])
+def test_batched_gather_equals_the_launch_by_launch_gather(monkeypatch, tabulated):
+    """one gather launch per frame (or per few shade launches when the rows run out: a 2 MB budget holds 3 of the 6 rows of this image)
+    adds the same terms as a launch per bounce, after instead of between the emission of a path's later bounces: equal to
+    rounding, far inside the radiance tolerance; every setting evaluates the same pairs and is reproducible bit for bit"""
+    kw = dict(tabulated=tabulated)
+    ref, st_ref = _render_c4(monkeypatch, {"RT_GATHER_BATCH": "0"}, **kw)
+    images = {}
+    for name, env in [("frame", {}), ("three_rows", {"RT_GATHER_BATCH_MB": "2"}), ("one_at_a_time", {"RT_FRAMES_IN_FLIGHT": "1"}),
+                      ("big_blocks", {"RT_GATHER_BLOCK": "1024", "RT_GATHER_GROUPS": "1"})]:
+        img, st = _render_c4(monkeypatch, env, **kw)
+        assert st["gather_pairs"] == st_ref["gather_pairs"] > 0
+        assert st["gather_launches"] < st_ref["gather_launches"]
+        a, b = img.astype(np.float64), ref.astype(np.float64)
+        rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-6)
+        assert rel.max() < 2e-6, "%s: batched and launch-by-launch gather differ by %g" % (name, rel.max())
+        images[name] = img
+    again, _ = _render_c4(monkeypatch, {}, **kw)
+    assert np.array_equal(again.view(np.uint32), images["frame"].view(np.uint32)), "the batched gather is not reproducible"
+    assert np.array_equal(images["big_blocks"].view(np.uint32), images["frame"].view(np.uint32)), "the result depends on the launch shape"

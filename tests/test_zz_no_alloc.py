@@ -31,7 +31,8 @@ def _render(rt, scene, static, frames):
                          ids=["bunny", "cornell_bunny_bssrdf"])
 def test_static_dispatch_equals_dispatch_twice_in_a_row(make, monkeypatch):
     from raytracer_amd import api
-    monkeypatch.setenv("RT_FRAMES_IN_FLIGHT", "1")   # the reference run: one frame at a time, like the static entry point
+    monkeypatch.setenv("RT_FRAMES_IN_FLIGHT", "1")   # the reference run: one frame at a time, like the static entry point,
+    monkeypatch.setenv("RT_GATHER_BATCH", "0")       # and a gather launch per bounce (the batched gather allocates its rows; it adds the same terms in another order: equal to rounding, tests/test_gpu_translucent.py)
     ref, sta = api.Raytracer(0), api.Raytracer(0)
     try:
         for (w, h) in ((256, 250), (101, 67)):       # 64 tiles (the limit), then 12 partly filled ones
