@@ -110,7 +110,7 @@ struct rt_ctx {
     // instead of one small launch per bounce -- per lane: nine arrays of rows x n_paths items, the rows' per-segment counts, the
     // numbering of the items (+ the launch's block counter)
     struct BatchGather { float* d_arena = nullptr; u32* d_counts = nullptr; u32* d_off = nullptr; u32 rows = 0, stride = 0, cols_cap = 0; };
-    BatchGather bg[2]; int gather_batch = 1; size_t gather_batch_mb = 3072; bool no_alloc_call = false; int gather_groups = 2, gather_block = 256; /* RT_GATHER_GROUPS, RT_GATHER_BLOCK: workgroups per CU of the batched launch, threads of each */
+    BatchGather bg[2]; int gather_batch = 1; size_t gather_batch_mb = 3072; bool no_alloc_call = false; int gather_fused = 1; /* RT_GATHER_FUSED: frames with the batched gather run the fused camera pass */ int gather_groups = 2, gather_block = 256; /* RT_GATHER_GROUPS, RT_GATHER_BLOCK: workgroups per CU of the batched launch, threads of each */
     int fuse_tail = 1; // RT_FUSE_TAIL: the last bounce's traversal kernel of the fused camera pass shades its hits itself
     int fuse_primary = 1; // RT_FUSE_PRIMARY: bounce 0 of the fused camera pass as one kernel in flat one-instance scenes (k_shade<.., TRACE>)
     int wave_major = 1; // RT_WAVE_MAJOR
@@ -138,7 +138,7 @@ struct rt_ctx {
     bool defer_resolve = false;            // run_pass: pipelined frame (k_frame_resolve instead of the resolve inside k_shade)
     // pipelined frames do not write the 8-bit render target; rt_read_render_target derives it from the accumulator
     // (k_resolve_only: the same expression on the same sums) when the last frames left it behind
-    bool render_target_stale = false; u32 render_target_frames = 0;
+    bool render_target_stale = false; u32 render_target_frames = 0; bool last_pass_lazy = false; // (run_pass: the camera pass left the render target to the next read)
     // BSSRDF tables
     float* d_table[2] = { nullptr, nullptr }; int table_texels[2] = { 0, 0 }; int profile = 0;
     // differences of consecutive scaled texels for k_gather<3> (ensure_gather_delta): valid for (table, factor) below
@@ -497,7 +497,7 @@ int ensure_batch_gather(rt_ctx* c, int lane, rt_ctx::BatchGather** out) {
     const uint64_t want = per_sample * c->g.samples_per_pixel;
     const uint64_t row_bytes = (uint64_t) 9 * 4 * c->n_paths;
     const uint64_t rows = std::min<uint64_t>(std::min<uint64_t>(want, (uint64_t) c->gather_batch_mb * (1ull << 20) / row_bytes), (uint64_t) 0xffffffffu / c->n_paths);
-    if (rows < 2) return RT_OK;
+    if (rows < 2 || rows < per_sample) return RT_OK; // (the rows of a sample are flushed together)
     rt_ctx::BatchGather& b = c->bg[lane];
     if (b.rows < rows || b.stride != c->n_paths || b.cols_cap != c->n_segments_cap) {
         RT_HIP(hipStreamSynchronize(c->stream)); // the lane's last frame may still read the old buffers
@@ -527,17 +527,24 @@ int run_pass(rt_ctx* c, bool probe) {
         int rc = launch_fill_capture(c->stream, a); if (rc) return rc;
     }
     bool gather = a.gather_enabled != 0;
-    // camera pass: no ray-generation kernel (bounce 0 derives rays from pixels), and unless the gather kernel can add
-    // emission after a path's last shade, no resolve kernel either (finished paths resolve their pixel in k_shade)
-    bool fused = !probe && !gather;
-    a.defer_resolve = (c->defer_resolve && fused) ? 1u : 0u;
-    a.lazy_render_target = c->defer_resolve ? 1u : 0u;
     // Batched gather: the shade launches that queue gather items write them to a row of their own; one k_gather launch evaluates
-    // the rows of the whole frame (or of as many launches as there are rows) and k_gather_apply adds the terms to the paths'
-    // radiance in the order of the rows.  The terms are the ones the launch-by-launch gather adds; a path's radiance sums them
-    // after, instead of between, the emission of its later bounces (radiance only: the 1e-4 contract; measured 1e-7).
+    // the rows of the whole frame (or of as many samples as there are rows for) and k_gather_apply adds the terms to the paths'
+    // radiance / the pixels' sample sums in the order of the rows.  The terms are the ones the launch-by-launch gather adds; a
+    // path's radiance sums them after, instead of between, the emission of its later bounces (radiance only: the 1e-4 contract;
+    // measured 1e-7).
     rt_ctx::BatchGather* bg = nullptr;
     if (gather && !a.hg.enabled) { int brc = ensure_batch_gather(c, c->cur_lane, &bg); if (brc) return brc; }
+    const u32 rows_per_sample = gather ? (u32) std::min<int64_t>(c->g.translucent_emission_bounces, c->g.bounces_per_sample) + 1u : 0u;
+    // camera pass: no ray-generation kernel (bounce 0 derives rays from pixels), and unless a gather launch adds emission to the
+    // paths' radiance between the bounces, no resolve kernel either: finished paths fold their sample into the pixel's sum in
+    // k_shade (`fused`).  With the batched gather that holds for frames with translucent meshes too: the terms are added to the
+    // sample sums after the last bounce, and the frame's resolve kernel adds the sums to the accumulator.
+    const bool fused_gather = gather && bg && c->gather_fused && !capture && !(c->flags & RT_FLAG_COUNT_TRAVERSAL) && c->persistent <= 0;
+    bool fused = !probe && (!gather || fused_gather);
+    a.defer_resolve = ((c->defer_resolve || fused_gather) && fused) ? 1u : 0u;
+    // (k_frame_resolve skips the pixels whose sample adds nothing, so it cannot keep the 8-bit target current: derived when it is read)
+    a.lazy_render_target = (c->defer_resolve || fused_gather) ? 1u : 0u;
+    if (!probe) c->last_pass_lazy = a.lazy_render_target != 0u;
     PassArgs ab = a; u32 bg_row = 0;
     auto gq_row = [&](PassArgs& x, u32 row) { // the gather queue of x: row `row` of the batch buffers
         const size_t rs = (size_t) bg->rows * bg->stride; float* p = bg->d_arena + (size_t) row * bg->stride;
@@ -553,42 +560,39 @@ int run_pass(rt_ctx* c, bool probe) {
     if (bg) {
         gq_row(ab, 0);
         ab.bg_cols = a.n_segments; ab.bg_stride = bg->stride; ab.bg_counts = bg->d_counts; ab.goff = bg->d_off;
+        ab.bg_to_sums = fused_gather ? 1u : 0u;
         ab.bg_block = (u32) c->gather_block; ab.bg_groups = (u32) c->gather_groups * c->cu_count; // two 256-thread workgroups per CU: 2 waves per SIMD.  The LDS (35 KB each) would allow four, and alone on the GPU the launch is fastest with four; beside the other frame's short, latency-bound launches two leave them the room they need (C4 8.55 against 8.1 Grays/s, profiles/r03_ab_gather_batch.txt)
     }
     for (u32 s = 0; s < c->g.samples_per_pixel; s++) {
         int rc = RT_OK;
         if (probe) { rc = launch_probe_raygen(c->stream, a, s); if (rc) return rc; }
+        // (the rows of a sample are flushed together, between samples: every path of the samples before has ended, so the pixels' sums exist)
+        if (bg && bg_row + rows_per_sample > bg->rows) { rc = flush_rows(); if (rc) return rc; }
         for (u32 b = 0; b <= c->g.bounces_per_sample; b++) {
             bool primary = !probe && b == 0;
-            if (primary && fused && a.fuse_primary) { rc = timed_primary_fused(c, a, s); if (rc) return rc; } // walk + shade in one kernel
-            else if (gather && bg) {
+            const bool gathers = gather && (int) b <= c->g.translucent_emission_bounces; // the translucent hits of this bounce emit (raytracing.hlsl:321)
+            PassArgs as_row; const PassArgs* as = &a;
+            if (bg && gathers) { as_row = a; gq_row(as_row, bg_row++); as = &as_row; } // this launch queues gather items: into the next row
+            if (primary && fused && a.fuse_primary) { rc = timed_primary_fused(c, *as, s); if (rc) return rc; } // walk + shade in one kernel
+            else if (gather && !fused) { // (the gather of the bounce before may still run on its side stream: the traversal does not care, the shade waits)
                 rc = timed_traverse(c, a, b & 1u, primary, s); if (rc) return rc;
-                if ((int) b <= c->g.translucent_emission_bounces) { // this shade queues gather items: into the next row
-                    PassArgs as = a; gq_row(as, bg_row);
-                    rc = launch_shade(c->stream, as, b & 1u, b, s, primary, fused); if (rc) return rc;
-                    if (++bg_row == bg->rows) { rc = flush_rows(); if (rc) return rc; }
-                } else { rc = launch_shade(c->stream, a, b & 1u, b, s, primary, fused); if (rc) return rc; }
-                continue;
-            }
-            else if (gather) { // (the gather of the bounce before may still run on its side stream: the traversal does not care, the shade waits)
-                rc = timed_traverse(c, a, b & 1u, primary, s); if (rc) return rc;
-                rc = gather_join(c); if (rc) return rc;
-                rc = launch_shade(c->stream, a, b & 1u, b, s, primary, fused); if (rc) return rc;
+                if (!bg) { rc = gather_join(c); if (rc) return rc; }
+                rc = launch_shade(c->stream, *as, b & 1u, b, s, primary, fused); if (rc) return rc;
             }
             else {
                 // the last bounce of the fused pass ends every path: its traversal kernel shades the hits itself (k_traverse, `tail`)
                 const bool tail_shade = c->fuse_tail && fused && !primary && !capture && b == c->g.bounces_per_sample && a.pool_groups == 0u && c->flat_instances != 2u &&
-                                        !(c->flags & RT_FLAG_COUNT_TRAVERSAL) && c->persistent <= 0;
+                                        !(c->flags & RT_FLAG_COUNT_TRAVERSAL) && c->persistent <= 0 && !gathers;
                 rc = timed_traverse(c, a, b & 1u, primary, s, tail_shade); if (rc) return rc;
-                if (!tail_shade) { rc = launch_shade(c->stream, a, b & 1u, b, s, primary, fused); if (rc) return rc; }
+                if (!tail_shade) { rc = launch_shade(c->stream, *as, b & 1u, b, s, primary, fused); if (rc) return rc; }
             }
-            if (gather && (int) b <= c->g.translucent_emission_bounces) { rc = gather_fork(c, a); if (rc) return rc; }
+            if (gathers && !bg) { rc = gather_fork(c, a); if (rc) return rc; }
         }
     }
     { int jrc = gather_join(c); if (jrc) return jrc; } // (a sample whose last bounce gathers: nothing after it has waited yet)
     { int frc = flush_rows(); if (frc) return frc; }
     if (probe) return launch_probe_resolve(c->stream, a);
-    if (fused && !c->defer_resolve) return RT_OK;
+    if (fused && !a.defer_resolve) return RT_OK;
     // pipelined frames: pixels are added to in frame order, by the frame's resolve kernel alone; all the tracing, shading
     // and gathering above overlaps the frame before
     if (c->accumulate_after) RT_HIP(hipStreamWaitEvent(c->stream, c->accumulate_after, 0));
@@ -911,6 +915,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_POOL")) c->pool = atoi(v);
     if (const char* v = getenv("RT_GATHER_L1")) c->gather_l1 = atoi(v);
     if (const char* v = getenv("RT_GATHER_BATCH")) c->gather_batch = atoi(v);
+    if (const char* v = getenv("RT_GATHER_FUSED")) c->gather_fused = atoi(v);
     if (const char* v = getenv("RT_GATHER_BLOCK")) { const int n = atoi(v); if (n == 256 || n == 512 || n == 1024) c->gather_block = n; }
     if (const char* v = getenv("RT_GATHER_GROUPS")) { const int n = atoi(v); if (n >= 1 && n <= 16) c->gather_groups = n; }
     if (const char* v = getenv("RT_GATHER_BATCH_MB")) { const long mb = atol(v); if (mb > 0) c->gather_batch_mb = (size_t) mb; }
@@ -1475,10 +1480,10 @@ int dispatch_serial(rt_ctx* c) {
     }
     rc = refresh_hg(); if (rc) return rc;
     rc = run_pass(c, false); if (rc) return rc;                                       // :734-741
-    c->render_target_stale = false;
     c->dispatch_index++;
     c->g.accumulator_count += 1;                                                      // :744
     c->g.translucent_accumulator_count += (c->flags & RT_FLAG_COLLECT_SAMPLES) ? 1u : 0u; // :745
+    c->render_target_stale = c->last_pass_lazy; c->render_target_frames = c->g.accumulator_count;
     return RT_OK;
 }
 } // namespace

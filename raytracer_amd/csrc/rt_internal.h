@@ -181,6 +181,7 @@ struct PassArgs {
     // evaluated by ONE k_gather launch (goff then numbers the items of all rows: bg_rows * bg_cols + 1 entries, then the block
     // counter of that launch); 0 = every shade launch is followed by its own gather launch
     u32 bg_rows, bg_cols, bg_stride, bg_groups, bg_block; // bg_groups workgroups of bg_block threads
+    u32 bg_to_sums;              // k_gather_apply adds the terms to the pixels' sample sums (fused camera pass) instead of the paths' radiance
     const u32* bg_counts;
     int* stack_spill;            // [48][n_paths] overflow of the per-lane traversal stack
     DeviceStats* stats;

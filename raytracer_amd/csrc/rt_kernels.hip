@@ -1032,8 +1032,26 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         if ((threadIdx.x & 63u) == 0) { frame_miss_mask(a)[qi >> 6] = m; frame_record_mask(a)[qi >> 6] = rec; }
     }
     u32 total;
+    // gather items of the translucent hits of this launch: compacted to the front of the segment's part of the gather queue
+    // (the host names a row of its own for every launch that can have any: batched gather, rt_api.hip run_pass)
+    auto queue_gather_items = [&]() {
+        u32 gtotal;
+        const u32 gslot = blockIdx.x * SEG + block_rank(gather, s_wave, gtotal);
+        if (threadIdx.x == 0) a.gseg_count[blockIdx.x] = gtotal;
+        if (gather) {
+            const GatherQueue& g = a.gq;
+            g.path[gslot] = path;
+            g.hx[gslot] = r.hit_point.x; g.hy[gslot] = r.hit_point.y; g.hz[gslot] = r.hit_point.z;
+            g.tf[gslot] = r.transmitted_fresnel;
+            g.kx[gslot] = thr_prev.x; g.ky[gslot] = thr_prev.y; g.kz[gslot] = thr_prev.z;
+            g.ti[gslot] = r.ti;
+        }
+    };
+    // the fused pass in a frame with the batched gather: only the bounces whose translucent hits emit have items (raytracing.hlsl:321)
+    const bool fused_gather = FUSED && a.gather_enabled != 0u && (int) bounce <= a.g.translucent_emission_bounces; // uniform
     if (tail) { // no path goes on: nothing to compact
         if (threadIdx.x == 0) a.seg_count[inq ^ 1u][blockIdx.x] = 0u;
+        if (fused_gather) queue_gather_items();
         return;
     }
     __shared__ u32 s_cnt[1025]; // up to 10 key bits (block_rank_hist)
@@ -1113,7 +1131,8 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             st.thr_x[o2] = s_stage[8][t]; st.thr_y[o2] = s_stage[9][t]; st.thr_z[o2] = s_stage[10][t];
             if (!rad_zero) { st.rad_x[o2] = s_stage[11][t]; st.rad_y[o2] = s_stage[12][t]; st.rad_z[o2] = s_stage[13][t]; }
         }
-        return; // the fused pass has no gather queue
+        if (fused_gather) queue_gather_items(); // (their terms are added to the pixels' sample sums at the end of the frame: k_gather_apply)
+        return;
     }
     u32 slot = blockIdx.x * SEG + rank_sorted(); // (sorted: the seven stores scatter inside the segment's 4 KB of each array)
     if (threadIdx.x == 0) a.seg_count[inq ^ 1u][blockIdx.x] = total;
@@ -1124,16 +1143,7 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         q.path[slot] = path;
     }
     if (!a.gather_enabled) return; // uniform: no translucent sample points in the scene
-    u32 gslot = blockIdx.x * SEG + block_rank(gather, s_wave, total);
-    if (threadIdx.x == 0) a.gseg_count[blockIdx.x] = total;
-    if (gather) {
-        const GatherQueue& g = a.gq;
-        g.path[gslot] = path;
-        g.hx[gslot] = r.hit_point.x; g.hy[gslot] = r.hit_point.y; g.hz[gslot] = r.hit_point.z;
-        g.tf[gslot] = r.transmitted_fresnel;
-        g.kx[gslot] = thr_prev.x; g.ky[gslot] = thr_prev.y; g.kz[gslot] = thr_prev.z;
-        g.ti[gslot] = r.ti;
-    }
+    queue_gather_items();
 }
 
 // ---- translucent_chit: sum of bssrdf(|p_i - hit|) * payload_i over all sample points (raytracing.hlsl:321-333) -------
@@ -1470,7 +1480,18 @@ __global__ __launch_bounds__(SEG) void k_gather_apply(PassArgs a) {
         if (threadIdx.x < cnt) {
             const size_t i = (size_t) r * a.bg_stride + (size_t) blockIdx.x * SEG + threadIdx.x;
             const u32 path = g.path[i];
-            a.ps.rad_x[path] += g.kx[i]; a.ps.rad_y[path] += g.ky[i]; a.ps.rad_z[path] += g.kz[i];
+            if (!a.bg_to_sums) { a.ps.rad_x[path] += g.kx[i]; a.ps.rad_y[path] += g.ky[i]; a.ps.rad_z[path] += g.kz[i]; }
+            else if (a.g.samples_per_pixel != 1u) { a.ps.sum_x[path] += g.kx[i]; a.ps.sum_y[path] += g.ky[i]; a.ps.sum_z[path] += g.kz[i]; }
+            else {
+                // fused pass, one sample per pixel: the finished paths left one float4 per pixel (k_shade), or, with the frame's
+                // masks in use, no record at all where the sample was (0, 0, 0, 1) -- the term then makes the record
+                float4* const s4 = (float4*) a.ps.sum_x;
+                bool have = true;
+                unsigned long long* const word = frame_record_mask(a) + (path >> 6);
+                if (frame_masks_in_use(a)) have = (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (path & 63u)) & 1ull; // (set by atomics of earlier rows: not through the L1)
+                if (have) { float4 v = s4[path]; v.x += g.kx[i]; v.y += g.ky[i]; v.z += g.kz[i]; s4[path] = v; }
+                else { s4[path] = make_float4(g.kx[i], g.ky[i], g.kz[i], 1.0f); atomicOr(word, 1ull << (path & 63u)); }
+            }
         }
         __syncthreads(); // the next row may name the same paths
     }
