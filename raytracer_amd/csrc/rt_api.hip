@@ -134,6 +134,12 @@ struct rt_ctx {
     float4 *d_sp_pay = nullptr, *d_sp_pay_alt = nullptr; // payloads of d_sp_read / d_sp_read_alt in Morton order (k_gather)
     RtSamplePoint* d_sp_read_alt = nullptr; hipEvent_t probe_done[2] = { nullptr, nullptr }; int last_probe_lane = -1;
     uint64_t sp_version = 0, sp_read_version[2] = { 0, 0 };
+    // With the batched gather nothing of a frame's camera pass reads the sample points before its gather launch at the end, so the
+    // sample-point pass (and the copy out of it) of a pipelined frame runs on a stream of its own, with path buffers of its own
+    // (a few segments: one path per point), beside the camera pass; the frame's gather launch waits for it (probe_wait).  The
+    // passes of consecutive frames stay in order by themselves: one stream.  RT_PROBE_SIDE=0: on the frame's lane, before its camera pass
+    int probe_side = 1; hipStream_t probe_stream = nullptr; PathBuffers probe_pb; u32 probe_paths = 0, probe_cap = 0;
+    hipEvent_t probe_wait = nullptr; bool lane_ran[2] = { false, false }; bool last_probe_side = false; // (last_probe_lane's pass ran on the probe stream)
     hipEvent_t accumulate_after = nullptr; // run_pass: the frame's resolve waits for this (the previous frame's end)
     bool defer_resolve = false;            // run_pass: pipelined frame (k_frame_resolve instead of the resolve inside k_shade)
     // pipelined frames do not write the 8-bit render target; rt_read_render_target derives it from the accumulator
@@ -152,7 +158,7 @@ struct rt_ctx {
     void* d_static_scratch = nullptr; // this GPU's copy of the static scratch array of rt_dispatch_rays_static (resolved at rt_create)
     double bluenoise_ms = 0; uint64_t bluenoise_points = 0; // wall time and result of the last rt_generate_translucent_samples
     hipEvent_t build_ev[2] = { nullptr, nullptr }; // bracket the builds of rt_build_blas / rt_build_tlas (created once: no error path can leak them)
-    rt_ctx() { memset(&g, 0, sizeof g); memset(q, 0, sizeof q); memset(&hits, 0, sizeof hits); memset(&ps, 0, sizeof ps); memset(st, 0, sizeof st); memset(&gq, 0, sizeof gq); memset(&alt, 0, sizeof alt); }
+    rt_ctx() { memset(&g, 0, sizeof g); memset(q, 0, sizeof q); memset(&hits, 0, sizeof hits); memset(&ps, 0, sizeof ps); memset(st, 0, sizeof st); memset(&gq, 0, sizeof gq); memset(&alt, 0, sizeof alt); memset(&probe_pb, 0, sizeof probe_pb); }
 };
 
 namespace {
@@ -252,6 +258,26 @@ int ensure_second_lane(rt_ctx* c) {
     return rc;
 }
 
+// the path buffers of the sample-point pass on its own stream (rt_ctx::probe_side) <-> the context's current set
+void swap_probe_buffers(rt_ctx* c) {
+    rt_ctx::PathBuffers& o = c->probe_pb;
+    std::swap(c->d_arena, o.d_arena); std::swap(c->d_seg_count, o.d_seg_count); std::swap(c->hits, o.hits); std::swap(c->ps, o.ps);
+    std::swap(c->gq, o.gq); std::swap(c->d_stack_spill, o.d_stack_spill);
+    for (int k = 0; k < 2; k++) { std::swap(c->q[k], o.q[k]); std::swap(c->st[k], o.st[k]); }
+    std::swap(c->n_paths, c->probe_paths); std::swap(c->n_segments_cap, c->probe_cap);
+}
+int ensure_probe_side(rt_ctx* c) {
+    if (!c->probe_stream) RT_HIP(hipStreamCreateWithFlags(&c->probe_stream, hipStreamNonBlocking));
+    const u32 segs = std::max((c->n_points + 1023u) / 1024u, 1u);
+    if (c->probe_pb.d_arena && c->probe_cap >= segs) return RT_OK;
+    RT_HIP(hipStreamSynchronize(c->probe_stream));
+    dev_free(c->probe_pb.d_arena); dev_free(c->probe_pb.d_seg_count); memset(&c->probe_pb, 0, sizeof c->probe_pb); c->probe_paths = 0; c->probe_cap = 0;
+    swap_probe_buffers(c);
+    int rc = alloc_path_buffers(c, segs);
+    swap_probe_buffers(c);
+    return rc;
+}
+
 // every entry point other than a pipelined dispatch starts here: lane 1 drained, so that work on `stream` is ordered
 // after everything before it as it would be with one stream
 int quiesce(rt_ctx* c) {
@@ -259,6 +285,8 @@ int quiesce(rt_ctx* c) {
         c->pipelined = false;
         RT_HIP(hipStreamSynchronize(c->alt_stream));
         RT_HIP(hipStreamSynchronize(c->own_stream));
+        if (c->probe_stream) RT_HIP(hipStreamSynchronize(c->probe_stream));
+        c->probe_wait = nullptr;
     }
     return RT_OK;
 }
@@ -552,8 +580,17 @@ int run_pass(rt_ctx* c, bool probe) {
         x.gq.kx = p + 5 * rs; x.gq.ky = p + 6 * rs; x.gq.kz = p + 7 * rs; x.gq.ti = (int*) (p + 8 * rs);
         x.gseg_count = bg->d_counts + (size_t) row * a.n_segments;
     };
+    // the frame's sample-point pass on its own stream (rt_dispatch_rays): what reads the points waits for it
+    auto wait_probe = [&]() -> int {
+        if (!c->probe_wait) return RT_OK;
+        hipEvent_t e = c->probe_wait; c->probe_wait = nullptr;
+        RT_HIP(hipStreamWaitEvent(c->stream, e, 0));
+        return RT_OK;
+    };
+    if (!probe && gather && !bg) { int wrc = wait_probe(); if (wrc) return wrc; } // the gather launch of the first bounce already reads them
     auto flush_rows = [&]() -> int {
         if (!bg || !bg_row) return RT_OK;
+        { int wrc = wait_probe(); if (wrc) return wrc; }
         ab.bg_rows = bg_row; bg_row = 0;
         return timed_gather(c, ab, c->stream, true);
     };
@@ -916,6 +953,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_GATHER_L1")) c->gather_l1 = atoi(v);
     if (const char* v = getenv("RT_GATHER_BATCH")) c->gather_batch = atoi(v);
     if (const char* v = getenv("RT_GATHER_FUSED")) c->gather_fused = atoi(v);
+    if (const char* v = getenv("RT_PROBE_SIDE")) c->probe_side = atoi(v);
     if (const char* v = getenv("RT_GATHER_BLOCK")) { const int n = atoi(v); if (n == 256 || n == 512 || n == 1024) c->gather_block = n; }
     if (const char* v = getenv("RT_GATHER_GROUPS")) { const int n = atoi(v); if (n >= 1 && n <= 16) c->gather_groups = n; }
     if (const char* v = getenv("RT_GATHER_BATCH_MB")) { const long mb = atol(v); if (mb > 0) c->gather_batch_mb = (size_t) mb; }
@@ -974,6 +1012,8 @@ void rt_destroy(rt_ctx* c) {
     (void) drain_timers(c);
     dev_free(c->alt.d_arena); dev_free(c->alt.d_seg_count);
     for (auto& b : c->bg) { dev_free(b.d_arena); dev_free(b.d_counts); dev_free(b.d_off); }
+    if (c->probe_stream) { (void) hipStreamSynchronize(c->probe_stream); (void) hipStreamDestroy(c->probe_stream); }
+    dev_free(c->probe_pb.d_arena); dev_free(c->probe_pb.d_seg_count);
     if (c->alt_stream) (void) hipStreamDestroy(c->alt_stream);
     for (int l = 0; l < 2; l++) { if (c->gather_stream[l]) { (void) hipStreamSynchronize(c->gather_stream[l]); (void) hipStreamDestroy(c->gather_stream[l]); }
                                   for (int k = 0; k < 2; k++) if (c->gather_ev[l][k]) (void) hipEventDestroy(c->gather_ev[l][k]); }
@@ -1525,7 +1565,7 @@ int rt_dispatch_rays(rt_ctx* c) {
             int rc = ensure_path_buffers(c); if (rc) return rc;
             rc = ensure_second_lane(c); if (rc) return rc;
             if (c->gather_side && gather) { rc = ensure_gather_side(c, 2); if (rc) return rc; }
-            c->pipelined = true; c->next_lane = 0; c->have_previous = false; c->last_probe_lane = -1;
+            c->pipelined = true; c->next_lane = 0; c->have_previous = false; c->last_probe_lane = -1; c->lane_ran[0] = c->lane_ran[1] = false; c->probe_wait = nullptr;
         }
         const int lane = c->next_lane;
         if (c->gather_side && gather && !c->gather_stream[1]) { int grc = ensure_gather_side(c, 2); if (grc) return grc; } // (the gather came on after the lanes were made)
@@ -1534,11 +1574,27 @@ int rt_dispatch_rays(rt_ctx* c) {
         swap_lane();
         int rc = RT_OK;
         auto hip_ok = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == RT_OK) { set_error("rt_dispatch_rays: %s failed: %s", what, hipGetErrorString(e)); rc = RT_ERR_DEVICE; } };
-        if (collect || (gather && c->sp_read_version[lane] != c->sp_version)) {
-            if (c->last_probe_lane >= 0 && c->last_probe_lane != lane) hip_ok(hipStreamWaitEvent(c->stream, c->probe_done[c->last_probe_lane], 0), "event wait");
+        const bool side = c->probe_side && c->gather_batch && gather && c->n_points > 0;
+        if (side && (collect || c->sp_read_version[lane] != c->sp_version)) {
+            // the pass on the probe stream, with its own path buffers; the stream keeps the passes of consecutive frames in order.  It
+            // writes this lane's copy of the points, which the gather of the lane's frame before may still read
+            rc = ensure_probe_side(c);
+            if (rc == RT_OK) {
+                swap_probe_buffers(c); std::swap(c->stream, c->probe_stream);
+                if (c->lane_ran[lane]) hip_ok(hipStreamWaitEvent(c->stream, c->lane_done[lane], 0), "event wait");
+                if (c->last_probe_lane >= 0 && !c->last_probe_side) hip_ok(hipStreamWaitEvent(c->stream, c->probe_done[c->last_probe_lane], 0), "event wait"); // (the pass before ran on its lane)
+                if (rc == RT_OK && collect) { rc = run_pass(c, true); if (rc == RT_OK) c->sp_version++; } // raytracing.cpp:677-687
+                if (rc == RT_OK) rc = refresh_read_points(c); // :723-728
+                if (rc == RT_OK) { c->sp_read_version[lane] = c->sp_version; hip_ok(hipEventRecord(c->probe_done[lane], c->stream), "event record"); c->last_probe_lane = lane; c->last_probe_side = true; }
+                std::swap(c->stream, c->probe_stream); swap_probe_buffers(c);
+                if (rc == RT_OK) c->probe_wait = c->probe_done[lane];
+            }
+        }
+        else if (collect || (gather && c->sp_read_version[lane] != c->sp_version)) {
+            if (c->last_probe_lane >= 0 && (c->last_probe_lane != lane || c->last_probe_side)) hip_ok(hipStreamWaitEvent(c->stream, c->probe_done[c->last_probe_lane], 0), "event wait");
             if (rc == RT_OK && collect) { rc = run_pass(c, true); if (rc == RT_OK) c->sp_version++; } // raytracing.cpp:677-687
             if (rc == RT_OK) rc = refresh_read_points(c); // :723-728
-            if (rc == RT_OK) { c->sp_read_version[lane] = c->sp_version; hip_ok(hipEventRecord(c->probe_done[lane], c->stream), "event record"); c->last_probe_lane = lane; }
+            if (rc == RT_OK) { c->sp_read_version[lane] = c->sp_version; hip_ok(hipEventRecord(c->probe_done[lane], c->stream), "event record"); c->last_probe_lane = lane; c->last_probe_side = false; }
         }
         if (rc == RT_OK) {
             c->accumulate_after = c->have_previous ? c->lane_done[lane ^ 1] : nullptr;
@@ -1546,7 +1602,8 @@ int rt_dispatch_rays(rt_ctx* c) {
             rc = run_pass(c, false);                                                  // :734-741
             c->defer_resolve = false; c->accumulate_after = nullptr;
         }
-        if (rc == RT_OK) hip_ok(hipEventRecord(c->lane_done[lane], c->stream), "event record");
+        if (rc == RT_OK && c->probe_wait) { hip_ok(hipStreamWaitEvent(c->stream, c->probe_wait, 0), "event wait"); c->probe_wait = nullptr; } // (a frame without a gather launch: the lane's end still means its points are written)
+        if (rc == RT_OK) { hip_ok(hipEventRecord(c->lane_done[lane], c->stream), "event record"); c->lane_ran[lane] = true; }
         swap_lane();
         c->cur_lane = 0;
         if (rc) return rc;
