@@ -135,7 +135,8 @@ typedef struct RtStats {
     uint64_t wave_tri_steps;       /* 64-lane wave; lane steps / (64 * wave steps) = SIMD efficiency of the traversal    */
     uint64_t wave_instance_steps;
     uint64_t max_ray_steps;        /* RT_FLAG_COUNT_TRAVERSAL: most node + triangle + instance steps taken by one ray */
-    uint64_t gather_launches;      /* launches of the BSSRDF gather kernel (translucent_chit's loop, raytracing.hlsl:323-331) */
+    uint64_t gather_launches;      /* launches of the BSSRDF gather kernel (translucent_chit's loop, raytracing.hlsl:323-331): one per frame */
+                                   /* (or per few samples) with the batched gather, else one per gathering bounce      */
     double   gather_ms;            /* their summed duration with RT_FLAG_TIME_KERNELS (HIP events on the context's stream) */
     uint64_t traverse_launches_timed; /* launches that traverse_ms covers (all of them, or every 8th dispatch with RT_FLAG_TIME_SAMPLED) */
     uint64_t gather_launches_timed;   /* launches that gather_ms covers */
@@ -151,7 +152,7 @@ typedef struct RtStats {
                                       /* kernels: traversal runs without the global overflow path; 0 = with it                     */
     uint32_t flat_depth;              /* > 0: the scene (<= 2 instances) is traversed in ONE tree over all instanced triangles, of   */
                                       /* this many inner-node levels, instead of the two levels; 0 = two levels */
-    uint32_t fused_bounce0;           /* 1 = camera dispatches without the BSSRDF gather walk AND shade bounce 0 in one kernel (flat one-instance */
+    uint32_t fused_bounce0;           /* 1 = camera dispatches (without the BSSRDF gather, or with the batched one) walk AND shade bounce 0 in one kernel (flat one-instance */
                                       /* scenes): that launch is counted in primary_launches / primary_ms, and no separate bounce-0 shade runs   */
     uint32_t fused_tail;              /* 1 = their last bounce is shaded inside its traversal kernel                                             */
     uint32_t tlas_grid_cells;         /* > 0: the top level of a two-level scene is walked as a uniform grid of that many cells (many evenly spread   */
@@ -234,8 +235,10 @@ int  rt_dispatch_rays(rt_ctx* ctx);
  * traversal-stack overflow) in a 27.5 MB static device array instead of buffers allocated on demand.  Calls no
  * hipMalloc / hipFree / event or stream creation.  Limits: at most 64 tiles of 32x32 pixels (e.g. 256x256) and 65,536
  * sample points, else RT_ERR_LIMIT; RT_FLAG_CAPTURE_HITS / RT_FLAG_TIME_KERNELS give RT_ERR_UNSUPPORTED (they
- * allocate).  Same results as rt_dispatch_rays, bit for bit.  All contexts on one GPU share the array: calls that
- * overlap on one GPU (two contexts, or two streams) race. */
+ * allocate).  Same results as rt_dispatch_rays, bit for bit -- except in frames with the BSSRDF gather, where rt_dispatch_rays
+ * batches the gather launches of a frame in rows it allocates (RT_GATHER_BATCH) and this entry point gathers bounce by bounce:
+ * the same terms added in another order, equal to rounding (1e-7 relative; bit for bit with RT_GATHER_BATCH=0).  All contexts
+ * on one GPU share the array: calls that overlap on one GPU (two contexts, or two streams) race. */
 int  rt_dispatch_rays_static(rt_ctx* ctx);
 
 /* ---- synchronisation and read-back -------------------------------------------------------------------- */

@@ -1746,7 +1746,8 @@ int rt_get_stats(rt_ctx* c, RtStats* out) {
     out->tlas_depth = (u32) c->tlas_depth; out->max_blas_depth = (u32) c->max_blas_depth;
     out->tlas_grid_cells = (c->flat_instances || c->persistent > 0) ? 0u : c->grid_cells;
     { PassArgs a; fill_pass_args(c, a, false); out->stack_in_lds = a.stack_in_lds;
-      const bool fused_pass = a.gather_enabled == 0u && !(c->flags & (RT_FLAG_COUNT_TRAVERSAL | RT_FLAG_CAPTURE_HITS));
+      const bool batched = c->gather_batch && c->gather_fused && !a.hg.enabled && (c->bg[0].rows || c->bg[1].rows); // frames with the batched gather run the fused pass too (run_pass)
+      const bool fused_pass = (a.gather_enabled == 0u || batched) && !(c->flags & (RT_FLAG_COUNT_TRAVERSAL | RT_FLAG_CAPTURE_HITS));
       out->fused_bounce0 = (fused_pass && a.fuse_primary) ? 1u : 0u;
       out->fused_tail = (fused_pass && c->fuse_tail && a.pool_groups == 0u && c->flat_instances != 2u && c->persistent <= 0) ? 1u : 0u; }
     out->flat_depth = c->flat_instances ? (uint32_t) c->flat_info.depth : 0u;
