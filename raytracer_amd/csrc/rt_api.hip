@@ -530,9 +530,14 @@ int ensure_batch_gather(rt_ctx* c, int lane, rt_ctx::BatchGather** out) {
     if (b.rows < rows || b.stride != c->n_paths || b.cols_cap != c->n_segments_cap) {
         RT_HIP(hipStreamSynchronize(c->stream)); // the lane's last frame may still read the old buffers
         dev_free(b.d_arena); dev_free(b.d_counts); dev_free(b.d_off); b.rows = 0;
-        RT_HIP(hipMalloc(&b.d_arena, rows * row_bytes));
-        RT_HIP(hipMalloc(&b.d_counts, sizeof(u32) * rows * c->n_segments_cap));
-        RT_HIP(hipMalloc(&b.d_off, sizeof(u32) * (rows * c->n_segments_cap + 2)));
+        if (hipMalloc(&b.d_arena, rows * row_bytes) != hipSuccess || hipMalloc(&b.d_counts, sizeof(u32) * rows * c->n_segments_cap) != hipSuccess ||
+            hipMalloc(&b.d_off, sizeof(u32) * (rows * c->n_segments_cap + 2)) != hipSuccess) {
+            // no room for the rows (they are an optimisation, not a need): this context gathers launch by launch from here on
+            (void) hipGetLastError();
+            dev_free(b.d_arena); dev_free(b.d_counts); dev_free(b.d_off);
+            c->gather_batch = 0;
+            return RT_OK;
+        }
         b.rows = (u32) rows; b.stride = c->n_paths; b.cols_cap = c->n_segments_cap;
     }
     *out = &b;

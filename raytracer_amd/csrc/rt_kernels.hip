@@ -941,7 +941,7 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
         if (active) {
             const RayQueue& q = a.q[inq];
             path = q.path[qi];
-            if (!tail) o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]);
+            if (!tail || (a.gather_enabled != 0u && (int) bounce <= a.g.translucent_emission_bounces)) o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]); // (a translucent hit of an emitting bounce queues its hit point)
             d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
             if (FUSED) { // the state travels with the ray
                 const SlotState& st = a.st[inq];

@@ -179,7 +179,19 @@ def test_top_level_rebuilds_between_pipelined_frames(monkeypatch):
     assert np.array_equal(images[0][1], images[1][1]) and images[0][0].any()
 
 
-@pytest.mark.parametrize("case", ["bunny_b1", "bunny_b3", "cornell_spp3", "cornell_bunny", "ragged_spp3"])
+def _double_dispatch(scene):
+    from raytracer_amd import _abi
+    scene.flags |= _abi.RT_FLAG_DOUBLE_DISPATCH   # raytracing.cpp:688-695: one frame at a time, the fused pass with its own resolve kernel
+    return scene
+
+
+def _emit_at_every_bounce(scene):
+    scene.globals.translucent_emission_bounces = scene.globals.bounces_per_sample  # the last bounce's translucent hits gather too
+    return scene
+
+
+@pytest.mark.parametrize("case", ["bunny_b1", "bunny_b3", "cornell_spp3", "cornell_bunny", "ragged_spp3", "cornell_bunny_emit_all",
+                                  "cornell_as_shipped", "cornell_as_shipped_emit_all_spp2", "cornell_bunny_double_dispatch"])
 def test_images_without_the_hit_tap_match_the_oracle(oracle_mod, case):
     """The ray-by-ray parity tests run with RT_FLAG_CAPTURE_HITS, which keeps the dispatches one at a time and the last
     shade of a frame complete.  The production path -- frames in flight, deferred resolve, lazy render target, and the
@@ -190,6 +202,12 @@ def test_images_without_the_hit_tap_match_the_oracle(oracle_mod, case):
     scene = {"bunny_b1": lambda: scenes.bunny(960, 540, spp=1, bounces=1), "bunny_b3": lambda: scenes.bunny(640, 360, spp=1, bounces=3),
              "cornell_spp3": lambda: scenes.cornell(480, 270, spp=3, bounces=4),
              "cornell_bunny": lambda: scenes.cornell_bunny(320, 180, spp=2, bounces=3),
+             # the batched gather in the fused pass: a gathering last bounce (its shade is emission-only),
+             # and the one-instance scene as shipped -- bounce 0 as one kernel, the last bounce shaded by its traversal kernel
+             "cornell_bunny_emit_all": lambda: _emit_at_every_bounce(scenes.cornell_bunny(320, 180, spp=1, bounces=2, sample_radius=0.04)),
+             "cornell_bunny_double_dispatch": lambda: _double_dispatch(scenes.cornell_bunny(256, 144, spp=2, bounces=2, sample_radius=0.05)),
+             "cornell_as_shipped": lambda: scenes.cornell(320, 180, spp=1, bounces=4, translucent_boxes=True, sample_radius=0.03),
+             "cornell_as_shipped_emit_all_spp2": lambda: _emit_at_every_bounce(scenes.cornell(256, 144, spp=2, bounces=2, translucent_boxes=True, sample_radius=0.04)),
              # tiles that are only partly inside the image, several samples per pixel, frames in flight: the per-thread
              # records and the miss / record masks of the deferred resolve on ragged tiles
              "ragged_spp3": lambda: scenes.bunny(333, 181, spp=3, bounces=2)}[case]()
@@ -201,7 +219,7 @@ def test_images_without_the_hit_tap_match_the_oracle(oracle_mod, case):
         pu.compare_images(ga, ca)
         gr, cr = gpu.read_render_target().astype(np.int32), cpu.read_render_target().astype(np.int32)
         assert np.abs(gr - cr).max() <= 1
-        if case != "cornell_bunny":   # no tolerance-covered arithmetic without the gather: the same floats, the same bytes
+        if "cornell_bunny" not in case and "as_shipped" not in case:   # no tolerance-covered arithmetic without the gather: the same floats, the same bytes
             assert np.array_equal(ga.view(np.uint32), ca.view(np.uint32)) and np.array_equal(gr, cr)
     finally:
         gpu.close(); cpu.close()

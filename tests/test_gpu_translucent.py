@@ -196,3 +196,60 @@ def test_batched_gather_equals_the_launch_by_launch_gather(monkeypatch, tabulate
     again, _ = _render_c4(monkeypatch, {}, **kw)
     assert np.array_equal(again.view(np.uint32), images["frame"].view(np.uint32)), "the batched gather is not reproducible"
     assert np.array_equal(images["big_blocks"].view(np.uint32), images["frame"].view(np.uint32)), "the result depends on the launch shape"
+
+
+def _life_of_a_context(monkeypatch, env):
+    """one context through changes of resolution, samples per pixel, emitting bounces and the SSS switch; the accumulator
+    after each stage"""
+    from raytracer_amd import api, distributed, _abi
+    for k in ("RT_GATHER_BATCH", "RT_FRAMES_IN_FLIGHT", "RT_PROBE_SIDE", "RT_GATHER_FUSED"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    s = scenes.cornell_bunny(160, 96, spp=2, bounces=3, sample_radius=0.04)
+    rt = api.Raytracer(0)
+    out = []
+    try:
+        s.setup(rt)
+        g = s.globals
+        for f in range(3):
+            distributed.render_frame(rt, g, f, 5)
+        out.append(rt.read_accumulator())
+        rt.update_resolution(224, 128)                    # larger: the path buffers and the rows of the batched gather are allocated again
+        g.camera_aspect = 224.0 / 128.0
+        for f in range(3):
+            distributed.render_frame(rt, g, f, 5)         # (frame 0 starts a new accumulation)
+        out.append(rt.read_accumulator())
+        g.samples_per_pixel, g.bounces_per_sample, g.translucent_emission_bounces = 3, 2, 2   # three rows per sample instead of two
+        for f in range(3, 5):
+            distributed.render_frame(rt, g, f, 5)
+        out.append(rt.read_accumulator())
+        flags = s.flags
+        rt.set_flags(flags & ~_abi.RT_FLAG_ENABLE_SSS)   # no gather, sample collection goes on (on the frame's lane)
+        distributed.render_frame(rt, g, 5, 5)
+        rt.set_flags(flags)
+        g.samples_per_pixel = 1                           # one sample per pixel: the frame's miss / record masks
+        for f in range(6, 10):
+            distributed.render_frame(rt, g, f, 5)
+        out.append(rt.read_accumulator())
+        out.append(np.concatenate([rt.read_sample_points(i)[0]["payload"] for i in range(rt.translucent_instance_count())]))
+        return out
+    finally:
+        rt.close()
+
+
+def test_batched_gather_through_changes_of_the_frame_parameters(monkeypatch):
+    ref = _life_of_a_context(monkeypatch, {"RT_GATHER_BATCH": "0"})
+    one = _life_of_a_context(monkeypatch, {"RT_FRAMES_IN_FLIGHT": "1"})
+    two = _life_of_a_context(monkeypatch, {})
+    lane = _life_of_a_context(monkeypatch, {"RT_PROBE_SIDE": "0"})
+    unfused = _life_of_a_context(monkeypatch, {"RT_GATHER_FUSED": "0"})
+    for k in range(len(ref)):
+        assert ref[k].any()
+        assert np.array_equal(one[k].view(np.uint32), two[k].view(np.uint32)), "stage %d: frames in flight change the image" % k
+        assert np.array_equal(lane[k].view(np.uint32), two[k].view(np.uint32)), "stage %d: the stream of the sample-point pass changes the image" % k
+        for name, img in (("fused", two[k]), ("unfused", unfused[k])):
+            a, b = img.astype(np.float64), ref[k].astype(np.float64)
+            rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-6)
+            assert rel.max() < 2e-6, "stage %d: batched (%s) and launch-by-launch gather differ by %g" % (k, name, rel.max())
+    assert np.array_equal(ref[-1].view(np.uint32), two[-1].view(np.uint32)), "the sample points' payloads do not depend on the gather"
