@@ -402,6 +402,18 @@ def main():
                            "achieved": pmc_all[k0]["SQ_INSTS_VALU"] / (ms0 * 1e-3) / 1e9, "unit": "Ginst/s",
                            "frac": pmc_all[k0]["SQ_INSTS_VALU"] / (ms0 * 1e-3) / 1e9 / (SIMDS * CLOCK_GHZ / cyc_best),
                            "traffic": pmc_all[k0].get("traffic_bytes_per_launch")}
+        # Flat one-instance scenes also run the queued bounces but the last as ONE kernel each (k_shade<false, true, N>: walk + shade,
+        # RT_FUSE_QUEUED): the library times those launches with the traversal launches, so the roofline's counters are the
+        # per-launch means over both kinds of launch, weighted by how often the passes saw each
+        queued_fused = [k for k in (pmc_all or {}) if k.startswith("k_shade<false, true, ") and not k.endswith(", 0>")]
+        if queued_fused and fused0:
+            entries = [pmc_all[k] for k in queued_fused] + ([pmc] if pmc else [])
+            n_all = sum(e["launches_sampled"] for e in entries)
+            merged = {"launches_sampled": n_all}
+            for f in set().union(*[set(e) for e in entries]):
+                if f != "launches_sampled" and all(isinstance(e.get(f), (int, float)) for e in entries):
+                    merged[f] = sum(e[f] * e["launches_sampled"] for e in entries) / n_all
+            pmc = merged
         if pmc is not None:
             traffic = pmc.get("traffic_bytes_per_launch")
             insts = pmc.get("SQ_INSTS_VALU")
@@ -480,7 +492,8 @@ def main():
                          # (selects, v_fma_mix, min / max run at half the fma rate on gfx950): how full the issue slots are
                          "frac_at_mix_cost": mix_frac, "valu_busy_pmc": valu_busy,
                          "frame_valu_insts": frame_insts, "frame_issue_frac_at_mix_cost": frame_issue_frac,
-                         "launches_of": "queued k_traverse launches (bounce 0 runs in k_shade<true, true, N>: bounce0_kernel)" if fused0 else "all k_traverse launches",
+                         "launches_of": ("queued launches: %s and the last bounce's k_traverse (bounce 0 runs in k_shade<true, true, N>: bounce0_kernel)" % ", ".join(sorted(queued_fused)) if queued_fused
+                                         else "queued k_traverse launches (bounce 0 runs in k_shade<true, true, N>: bounce0_kernel)") if fused0 else "all k_traverse launches",
                          "bounce0_kernel": bounce0,
                          "mean_launch_ms": mean_launch_ms, "rays_per_launch": rays_per_launch,
                          "traverse_Mrays_s": rays_timed / (stats["traverse_ms"] * 1e-3) / 1e6 if stats["traverse_ms"] > 0 else None,
@@ -522,7 +535,10 @@ def main():
             pairs_s = stats["gather_pairs"] * gtimed / stats["gather_launches"] / (stats["gather_ms"] * 1e-3)
             out["gather"] = {"kernel": "k_gather", "pairs_per_s": pairs_s, "lds_GB_per_s": 24.0 * pairs_s / 1e9,
                              "mean_launch_ms": stats["gather_ms"] / gtimed,
-                             "share_of_step": stats["gather_ms"] / gtimed * stats["gather_launches"] / (sum(block_s) * 1e3)}
+                             "share_of_step": stats["gather_ms"] / gtimed * stats["gather_launches"] / (sum(block_s) * 1e3),
+                             # 1 with the batched gather (one launch per frame over the items of all its gathering shade launches, with its
+                             # numbering and apply kernels inside the timed bracket), else one per gathering bounce (RT_GATHER_BATCH)
+                             "launches_per_step": stats["gather_launches"] / max(len(block_s) * args.steps, 1)}
             gp = (pmc_all or {}).get("k_gather")
             if gp and gp.get("SQ_INSTS_VALU") and cyc_best:
                 # second roofline: the gather is bound by vector-instruction issue too (sqrt / filter arithmetic per pair)

@@ -112,6 +112,7 @@ struct rt_ctx {
     struct BatchGather { float* d_arena = nullptr; u32* d_counts = nullptr; u32* d_off = nullptr; u32 rows = 0, stride = 0, cols_cap = 0; };
     BatchGather bg[2]; int gather_batch = 1; size_t gather_batch_mb = 3072; bool no_alloc_call = false; int gather_fused = 1; /* RT_GATHER_FUSED: frames with the batched gather run the fused camera pass */ int gather_groups = 2, gather_block = 256; /* RT_GATHER_GROUPS, RT_GATHER_BLOCK: workgroups per CU of the batched launch, threads of each */
     int fuse_tail = 1; // RT_FUSE_TAIL: the last bounce's traversal kernel of the fused camera pass shades its hits itself
+    int fuse_queued = 1 << 30; // RT_FUSE_QUEUED: the queued bounces (up to this one) of the fused camera pass as one kernel each (walk + shade) in flat one-instance scenes; 0 = none
     int fuse_primary = 1; // RT_FUSE_PRIMARY: bounce 0 of the fused camera pass as one kernel in flat one-instance scenes (k_shade<.., TRACE>)
     int wave_major = 1; // RT_WAVE_MAJOR
     int xcd_bands = 1;  // RT_XCD_BANDS
@@ -447,6 +448,21 @@ int timed_primary_fused(rt_ctx* c, const PassArgs& a, u32 sample_index) {
     return rc;
 }
 
+// a queued bounce as one kernel (walk + shade): counted and timed as that bounce's traversal launch
+int timed_queued_fused(rt_ctx* c, const PassArgs& a, u32 inq, u32 bounce, u32 sample_index) {
+    bool timing = timing_now(c);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) {
+        RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
+        RT_HIP(hipEventRecord(e0, c->stream));
+        c->traverse_launches_timed++;
+    }
+    int rc = launch_shade(c->stream, a, inq, bounce, sample_index, false, true, true);
+    if (timing) { RT_HIP(hipEventRecord(e1, c->stream)); c->timed.emplace_back(e0, e1); }
+    c->traverse_launches++;
+    return rc;
+}
+
 int timed_gather(rt_ctx* c, const PassArgs& a, hipStream_t stream, bool batched = false) {
     bool timing = timing_now(c);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -625,8 +641,13 @@ int run_pass(rt_ctx* c, bool probe) {
                 // the last bounce of the fused pass ends every path: its traversal kernel shades the hits itself (k_traverse, `tail`)
                 const bool tail_shade = c->fuse_tail && fused && !primary && !capture && b == c->g.bounces_per_sample && a.pool_groups == 0u && c->flat_instances != 2u &&
                                         !(c->flags & RT_FLAG_COUNT_TRAVERSAL) && c->persistent <= 0 && !gathers;
-                rc = timed_traverse(c, a, b & 1u, primary, s, tail_shade); if (rc) return rc;
-                if (!tail_shade) { rc = launch_shade(c->stream, *as, b & 1u, b, s, primary, fused); if (rc) return rc; }
+                // the queued bounces in between, in flat one-instance scenes: one kernel that walks and shades, like bounce 0 (RT_FUSE_QUEUED)
+                const bool walk_and_shade = (int) b <= c->fuse_queued && fused && !primary && !tail_shade && a.fuse_primary && !capture;
+                if (walk_and_shade) { rc = timed_queued_fused(c, *as, b & 1u, b, s); if (rc) return rc; }
+                else {
+                    rc = timed_traverse(c, a, b & 1u, primary, s, tail_shade); if (rc) return rc;
+                    if (!tail_shade) { rc = launch_shade(c->stream, *as, b & 1u, b, s, primary, fused); if (rc) return rc; }
+                }
             }
             if (gathers && !bg) { rc = gather_fork(c, a); if (rc) return rc; }
         }
@@ -953,6 +974,7 @@ int create_context(rt_ctx* c) {
     if (const char* v = getenv("RT_WAVE_MAJOR")) c->wave_major = atoi(v);
     if (const char* v = getenv("RT_FUSE_PRIMARY")) c->fuse_primary = atoi(v);
     if (const char* v = getenv("RT_FUSE_TAIL")) c->fuse_tail = atoi(v);
+    if (const char* v = getenv("RT_FUSE_QUEUED")) c->fuse_queued = atoi(v);
     if (const char* v = getenv("RT_GATHER_SIDE")) c->gather_side = atoi(v);
     if (const char* v = getenv("RT_POOL")) c->pool = atoi(v);
     if (const char* v = getenv("RT_GATHER_L1")) c->gather_l1 = atoi(v);

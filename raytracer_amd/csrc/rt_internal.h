@@ -205,7 +205,8 @@ int launch_probe_raygen(hipStream_t s, const PassArgs& a, u32 sample_index);
 // tail_shade (queued launches, last bounce of the fused camera pass): the kernel shades its hits itself, no launch_shade follows
 int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_traversal, bool primary, u32 sample_index, bool tail_shade = false);
 // fused: finished camera paths resolve their pixel in the shade kernel (no launch_camera_resolve afterwards)
-int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index, bool primary, bool fused);
+// walk (queued bounces of the fused pass, flat one-instance scenes: PassArgs::fuse_primary): the kernel walks its rays itself, no launch_traverse before it
+int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index, bool primary, bool fused, bool walk = false);
 int launch_gather(hipStream_t s, const PassArgs& a);
 // batched gather: one launch for the items of a.bg_rows shade launches (a.gq = row 0), then their terms added to the paths' radiance row by row
 int launch_gather_batched(hipStream_t s, const PassArgs& a);

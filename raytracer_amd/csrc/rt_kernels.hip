@@ -904,7 +904,7 @@ __global__ __launch_bounds__(POOL_RAYS, 2) void k_traverse_pool(PassArgs a, u32 
 // the ranking in between starts with a barrier).
 template <bool PRIMARY, bool FUSED, int TRACE = 0>
 __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounce, u32 sample_index) { // 8 waves per SIMD = two workgroups per CU: at most 64 VGPRs
-    static_assert(TRACE == 0 || (PRIMARY && FUSED && (TRACE == 1 || TRACE == 3)), "the fused bounce-0 kernel walks a flat tree of one instance");
+    static_assert(TRACE == 0 || (FUSED && (TRACE == 1 || TRACE == 3)), "the kernels that walk and shade walk a flat tree of one instance");
     extern __shared__ int s_dyn[]; // TRACE: max(a.flat_rows, 14) x 1024 words
     __shared__ u32 s_wave[SEG / 64];
     const u32 qi = blockIdx.x * SEG + threadIdx.x;
@@ -936,14 +936,20 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             primary_ray(a, px, py, path, sample_index, rng, o, d);
         }
     } else {
+        if (TRACE > 0 && blockIdx.x == 0 && threadIdx.x < 64u) { // ray statistics, as k_traverse keeps them: one wave sums the segment counts of this launch
+            u32 sum = 0;
+            for (u32 k = threadIdx.x; k < a.n_segments; k += 64u) sum += a.seg_count[inq][k] & SEG_FILL_MASK;
+            sum = wave_sum(sum);
+            if (threadIdx.x == 0) atomicAdd(&a.stats->rays_camera, (unsigned long long) sum);
+        }
         const u32 fill = a.seg_count[inq][blockIdx.x];
         active = threadIdx.x < (fill & SEG_FILL_MASK);
         if (active) {
             const RayQueue& q = a.q[inq];
-            path = q.path[qi];
-            if (!tail || (a.gather_enabled != 0u && (int) bounce <= a.g.translucent_emission_bounces)) o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]); // (a translucent hit of an emitting bounce queues its hit point)
+            if (TRACE == 0) path = q.path[qi];
+            if (TRACE > 0 || !tail || (a.gather_enabled != 0u && (int) bounce <= a.g.translucent_emission_bounces)) o = mk3(q.ox[qi], q.oy[qi], q.oz[qi]); // (a translucent hit of an emitting bounce queues its hit point)
             d = mk3(q.dx[qi], q.dy[qi], q.dz[qi]);
-            if (FUSED) { // the state travels with the ray
+            if (FUSED && TRACE == 0) { // the state travels with the ray (TRACE: fetched after the walk, below -- eight registers that need not live through it)
                 const SlotState& st = a.st[inq];
                 if (!rng_dead) rng = st.rng[qi];
                 thr_prev = mk3(st.thr_x[qi], st.thr_y[qi], st.thr_z[qi]);
@@ -961,11 +967,20 @@ __global__ __launch_bounds__(SEG, 8) void k_shade(PassArgs a, u32 inq, u32 bounc
             LaneStack<false> st; st.lds = (RT_LDS int*) &s_dyn[(threadIdx.x >> 6) * a.flat_rows * TRAVERSE_WAVE + (threadIdx.x & 63u)];
             st.spill = nullptr; st.spill_stride = 0; st.sp = 0;
             TraverseCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.insts = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.inst_trips = 0;
-            trace_flat<1, LaneStack<false>, false, false, true, TRACE == 3>(a.scene, o, d, a.tmin, a.tmax, st, h, cnt);
+            trace_flat<1, LaneStack<false>, false, !PRIMARY, PRIMARY, TRACE == 3>(a.scene, o, d, a.tmin, a.tmax, st, h, cnt); // (queued rays: the speculative walk, like k_traverse's)
             if (h.inst < 0) { h.t = inf_f32(); h.u = 0.0f; h.v = 0.0f; h.tri = -1; }
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the last stack store has landed before the rows are reused (pool_barrier: hipcc can drop the barrier's own wait)
 #endif
+            if (!PRIMARY) { // the path's state, as the other kernels fetch it before the hit record
+                const RayQueue& q = a.q[inq];
+                const SlotState& sst = a.st[inq];
+                const u32 fill = a.seg_count[inq][blockIdx.x];
+                path = q.path[qi];
+                if (!rng_dead) rng = sst.rng[qi];
+                thr_prev = mk3(sst.thr_x[qi], sst.thr_y[qi], sst.thr_z[qi]);
+                if (!(fill & SEG_RAD_ZERO)) rad = mk3(sst.rad_x[qi], sst.rad_y[qi], sst.rad_z[qi]);
+            }
         } else {
         const float4 rec = ((const float4*) a.hits.t)[qi]; // (t, u, v, id) as k_traverse wrote it
         h.inst = __float_as_int(rec.w); h.t = inf_f32(); h.u = 0.0f; h.v = 0.0f; h.tri = -1;
@@ -1734,7 +1749,7 @@ int launch_traverse(hipStream_t s, const PassArgs& a, u32 in_queue, bool count_t
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
-int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index, bool primary, bool fused) {
+int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32 sample_index, bool primary, bool fused, bool walk) {
     size_t n = pass_paths(a);
     if (!n) return RT_OK;
     dim3 grid(a.n_segments), block(SEG);
@@ -1746,6 +1761,16 @@ int launch_shade(hipStream_t s, const PassArgs& a, u32 in_queue, u32 bounce, u32
         } else {
             RT_HIP(hipFuncSetAttribute((const void*) k_shade<true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
             hipLaunchKernelGGL((k_shade<true, true, 1>), grid, block, lds, s, a, in_queue, bounce, sample_index);
+        }
+    }
+    else if (!primary && fused && walk) { // a queued bounce in one kernel: walk and shade (no launch_traverse before it)
+        const size_t lds = (size_t) (a.flat_rows > 14u ? a.flat_rows : 14u) * SEG * sizeof(int);
+        if (a.scene.flat_inl_inst >= 0) {
+            RT_HIP(hipFuncSetAttribute((const void*) k_shade<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            hipLaunchKernelGGL((k_shade<false, true, 3>), grid, block, lds, s, a, in_queue, bounce, sample_index);
+        } else {
+            RT_HIP(hipFuncSetAttribute((const void*) k_shade<false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            hipLaunchKernelGGL((k_shade<false, true, 1>), grid, block, lds, s, a, in_queue, bounce, sample_index);
         }
     }
     else if (primary && fused) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, s, a, in_queue, bounce, sample_index);
