@@ -260,6 +260,10 @@ def main():
     if not args.dump_accumulator and block_s[0] < 0.05:
         for _ in range(min(int(0.05 / max(block_s[0], 1e-6)), 63)):
             block_s.append(timed_block())
+    elif not args.dump_accumulator and block_s[0] < 1.0:
+        # longer blocks of many-launch frames (C3: 450 launches per frame and lane) still spread by ~3 % from block to block with how
+        # the two lanes' launches happen to interleave: the median of three
+        block_s += [timed_block(), timed_block()]
     dt_block = sorted(block_s)[len(block_s) // 2] if len(block_s) > 1 else block_s[0]
     # the one exchange step of the job, after its last frame: timed between fences of its own and ADDED to the block
     fence()
