@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--split", choices=["sample", "tile"], default=None,
                     help="N > 1: sample-set split (frames r, r+N, ... per rank; default) or tile split (32x32 tiles t % N == r "
                          "of every frame; default for --workload c4)")
+    ap.add_argument("--probe-split", action="store_true",
+                    help="tile split: partition the sample-point pass over the ranks too and all-gather the payload blocks after every pass "
+                         "(distributed.install_probe_exchange; SURVEY 8e-i).  Default: every rank runs the whole pass, no exchange inside a frame")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a one-GPU box: every rank uses GPU 0 and the collectives go through gloo (checks the "
                          "multi-rank code path; the numbers mean nothing)")
@@ -190,6 +193,8 @@ def main():
     tile = dist is not None and args.split == "tile"
     if tile:
         rt.set_tile_split(rank, world)
+        if args.probe_split and points:   # the sample-point pass in blocks, the payloads all-gathered behind every pass
+            distributed.install_probe_exchange(rt, dist, rank, world, torch.device("cuda", local_rank), via_host=args.rehearse)
     elif dist is not None and points:
         distributed.require_no_sample_points(rt)   # payloads accumulate frame by frame: such scenes shard by tiles
     acc_ptr, acc_bytes = rt.accumulator_device_ptr()
@@ -292,7 +297,9 @@ def main():
     n_blocks = len(block_s)
     rays = (stats["rays_camera"] + stats["rays_probe"]) / n_blocks         # per block of K steps (the blocks are statistically alike)
     # the tile split replicates the (small) sample-point pass on every rank: those rays are counted once
-    job_rays = (stats["rays_camera"] + (stats["rays_probe"] if (not tile or rank == 0) else 0)) / n_blocks
+    # (with --probe-split the pass is partitioned: every rank counts its own block's rays)
+    probe_blocks = tile and args.probe_split and points
+    job_rays = (stats["rays_camera"] + (stats["rays_probe"] if (not tile or rank == 0 or probe_blocks) else 0)) / n_blocks
     t_rays = torch.tensor([float(job_rays), dt], dtype=torch.float64, device="cuda")
     if dist is not None:
         tmax = t_rays.clone()
@@ -302,6 +309,9 @@ def main():
     else:
         total_rays, dt_max = float(job_rays), dt
 
+    if probe_blocks:   # what follows is rank 0's own business: no collective may hide in it
+        rt.set_probe_exchange(None)
+        rt.set_probe_split(0, 1)
     if rank == 0:
         # traversal counters of this GPU's own BVH (one extra untimed frame with the counting kernel variant)
         rt.set_flags(scene.flags | _abi.RT_FLAG_COUNT_TRAVERSAL)
@@ -479,7 +489,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": args.width, "height": args.height, "triangles": scene.triangle_count(),
                        "sample_points": points, "rays_per_step_per_gpu": rays / args.steps,
-                       "parallelism": split_label + " + RCCL reduce" if world > 1 else "single GPU",
+                       "parallelism": (split_label + " + RCCL reduce" if world > 1 else "single GPU") +
+                                      (", sample-point pass in blocks + all-gather" if (tile and args.probe_split and points) else ""),
                        # consecutive steps overlap pairwise on the GPU (the library's default, RT_FRAMES_IN_FLIGHT)
                        "frames_in_flight": out_frames_in_flight(args)},
             "primary_Mrays_s": primary,        # bounce-0 launches alone (coherent), from their launch durations

@@ -30,7 +30,8 @@ extern "C" {
 /* 2: RtStats as it stands below (it grew after version 1 shipped), rt_dispatch_rays_static, rt_resolve_render_target_frames,
  *    rt_tile_pack_bytes / rt_pack_tiles / rt_unpack_tiles.  A caller compares rt_abi_version() with the RT_ABI_VERSION it was
  *    built against before it passes any struct (raytracer_amd/api.py and host/raytracing.hpp do). */
-#define RT_ABI_VERSION 2
+/* 3: rt_set_probe_split, rt_set_probe_exchange (no struct changed). */
+#define RT_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------------------------- */
 enum {
@@ -275,6 +276,21 @@ int  rt_resolve_render_target_frames(rt_ctx* ctx, uint32_t total_frames);
 int  rt_tile_pack_bytes(rt_ctx* ctx, uint32_t world, size_t* bytes);
 int  rt_pack_tiles(rt_ctx* ctx, uint32_t rank, uint32_t world, void* dev_packed);
 int  rt_unpack_tiles(rt_ctx* ctx, uint32_t rank, uint32_t world, const void* dev_packed);
+/* Tile split with the sample-point pass partitioned too (by default every rank runs the whole pass -- it is
+ * 0.2 % of a C4 frame -- and no rank needs another's payloads).  rt_set_probe_split: the translucent_rgen dispatches of this
+ * context trace only block `rank` of `world` equal blocks of the sample points (all instances concatenated in creation order;
+ * block = ceil(n / world) points, the last one short); the payloads of the other blocks are left as they are.
+ * rt_set_probe_exchange: `fn` is called by rt_dispatch_rays right after it has enqueued a sample-point pass, with the HIP
+ * stream the pass runs on (hipStream_t as void*), the device array of all n points (RtSamplePoint[n], the write buffer,
+ * raytracing.cpp:607-621) and the block size: it enqueues ON THAT STREAM (or completes before it returns) an all-gather
+ * of the ranks' blocks into the array -- block r = points [r * block, min((r + 1) * block, n)) -- and returns 0.  What reads
+ * the points afterwards (the copy of raytracing.cpp:723-728, the frame's gather launch) is ordered behind it; in pipelined
+ * frames that stream is the library's sample-point stream, so the exchange runs beside the frame's camera pass.  A point's
+ * payload is computed by exactly one rank with the one-GPU arithmetic: after the exchange every rank holds the one-GPU
+ * payloads bit for bit.  fn = NULL: no exchange (default).  raytracer_amd/distributed.py: install_probe_exchange. */
+typedef int (*rt_probe_exchange_fn)(void* user, void* hip_stream, void* dev_points, uint32_t n_points, uint32_t block_points);
+int  rt_set_probe_split(rt_ctx* ctx, uint32_t rank, uint32_t world);
+int  rt_set_probe_exchange(rt_ctx* ctx, rt_probe_exchange_fn fn, void* user);
 
 #ifdef __cplusplus
 }

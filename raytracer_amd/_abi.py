@@ -11,7 +11,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 DATA_DIR = os.path.join(PKG_DIR, "data")
 
-RT_ABI_VERSION = 2   # include/rt_abi.h
+RT_ABI_VERSION = 3   # include/rt_abi.h
 RT_OK = 0
 RT_SHADER_LAMBERT, RT_SHADER_LIGHT, RT_SHADER_TRANSLUCENT = 0, 1, 2
 RT_FLAG_COLLECT_SAMPLES = 1 << 0
@@ -182,6 +182,28 @@ class Backend(object):
 
     def set_tile_split(self, rank, world):
         self._call("set_tile_split", C.c_uint32(rank), C.c_uint32(world))
+
+    def set_probe_split(self, rank, world):
+        self._call("set_probe_split", C.c_uint32(rank), C.c_uint32(world))
+
+    def set_probe_exchange(self, fn):
+        """fn(stream_ptr, points_ptr, n_points, block_points) -> 0, called after every sample-point pass (include/rt_abi.h);
+        None removes it.  The ctypes thunk is kept alive on this object."""
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32)
+
+        def thunk(user, stream, points, n, block):
+            try:
+                return int(fn(stream or 0, points or 0, n, block) or 0)
+            except Exception:   # an exception must not unwind through the C caller
+                import traceback
+                traceback.print_exc()
+                return 1
+        keep = proto(thunk) if fn is not None else proto()   # (no argument: a NULL function pointer)
+        f = self._fn("set_probe_exchange")
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, proto, C.c_void_p]
+        self._check(f(self.h, keep, None), "set_probe_exchange")
+        self._probe_exchange_thunk = keep   # (the previous thunk may be released only now)
 
     def dispatch_rays(self):
         self._call("dispatch_rays")

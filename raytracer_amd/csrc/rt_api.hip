@@ -93,6 +93,8 @@ struct rt_ctx {
     float* d_accumulator = nullptr; uint8_t* d_render_target = nullptr;
     RtHit* d_capture = nullptr; size_t capture_records = 0; u32 capture_bounces = 0;
     u32 tile_rank = 0, tile_world = 1;
+    // sample-point pass partitioned over ranks (rt_set_probe_split) and the caller's exchange of the payload blocks after it (rt_set_probe_exchange)
+    u32 probe_rank = 0, probe_world = 1; rt_probe_exchange_fn probe_exchange = nullptr; void* probe_exchange_user = nullptr;
     // path buffers
     u32 n_paths = 0; float* d_arena = nullptr;
     RayQueue q[2]; HitBuf hits; PathState ps; SlotState st[2]; GatherQueue gq; int* d_stack_spill = nullptr;
@@ -394,6 +396,8 @@ void fill_pass_args(rt_ctx* c, PassArgs& a, bool probe) {
     a.accumulator = c->d_accumulator; a.render_target = c->d_render_target;
     a.sp_read = c->d_sp_read; a.sp_write = c->d_sp_write; a.sp_normal = c->d_sp_normal; a.sp_slice = c->d_sp_slice;
     a.n_points = c->n_points;
+    { const u32 block = (c->n_points + c->probe_world - 1) / c->probe_world; // equal blocks, the last one short (or empty)
+      a.probe_lo = std::min(c->probe_rank * block, c->n_points); a.probe_hi = std::min(a.probe_lo + block, c->n_points); }
     a.hg.nodes = c->d_hg_nodes; a.hg.sums = c->d_hg_sums; a.hg.pos = c->d_hg_pos; a.hg.pay = c->d_hg_pay;
     a.hg.order = c->d_hg_order; a.hg.slices = c->d_hg_slices; a.hg.max_solid_angle = c->hg_max_solid_angle;
     a.hg.enabled = (c->hg_enabled && c->hg_built) ? 1u : 0u;
@@ -1524,6 +1528,18 @@ int refresh_read_points(rt_ctx* c) {
     return RT_OK;
 }
 
+// translucent_rgen (raytracing.cpp:677-687) on c->stream, and -- multi-GPU with a partitioned pass -- the caller's exchange of the
+// payload blocks, enqueued on the same stream right behind it: everything that reads the points afterwards is ordered after both
+int sample_pass(rt_ctx* c) {
+    int rc = run_pass(c, true); if (rc) return rc;
+    if (c->probe_exchange) {
+        const u32 block = (c->n_points + c->probe_world - 1) / c->probe_world;
+        const int xrc = c->probe_exchange(c->probe_exchange_user, (void*) c->stream, (void*) c->d_sp_write, c->n_points, block);
+        if (xrc) { set_error("rt_dispatch_rays: the sample-point exchange callback failed with %d", xrc); return RT_ERR_DEVICE; }
+    }
+    return RT_OK;
+}
+
 // one frame on c->stream with the context's current set of path buffers, nothing else in flight (the order of
 // raytracing.cpp:652-747)
 int dispatch_serial(rt_ctx* c) {
@@ -1538,7 +1554,7 @@ int dispatch_serial(rt_ctx* c) {
         PassArgs a; fill_pass_args(c, a, false);
         return launch_hg_sums(c->stream, a, (u32) c->slices.size());
     };
-    if (collect) { rc = run_pass(c, true); if (rc) return rc; }                       // raytracing.cpp:677-687
+    if (collect) { rc = sample_pass(c); if (rc) return rc; }                          // raytracing.cpp:677-687
     if (c->flags & RT_FLAG_DOUBLE_DISPATCH) { rc = refresh_hg(); if (rc) return rc; }
     if (c->flags & RT_FLAG_DOUBLE_DISPATCH) { rc = run_pass(c, false); if (rc) return rc; } // :688-695
     if (collect) {
@@ -1610,7 +1626,7 @@ int rt_dispatch_rays(rt_ctx* c) {
                 swap_probe_buffers(c); std::swap(c->stream, c->probe_stream);
                 if (c->lane_ran[lane]) hip_ok(hipStreamWaitEvent(c->stream, c->lane_done[lane], 0), "event wait");
                 if (c->last_probe_lane >= 0 && !c->last_probe_side) hip_ok(hipStreamWaitEvent(c->stream, c->probe_done[c->last_probe_lane], 0), "event wait"); // (the pass before ran on its lane)
-                if (rc == RT_OK && collect) { rc = run_pass(c, true); if (rc == RT_OK) c->sp_version++; } // raytracing.cpp:677-687
+                if (rc == RT_OK && collect) { rc = sample_pass(c); if (rc == RT_OK) c->sp_version++; } // raytracing.cpp:677-687
                 if (rc == RT_OK) rc = refresh_read_points(c); // :723-728
                 if (rc == RT_OK) { c->sp_read_version[lane] = c->sp_version; hip_ok(hipEventRecord(c->probe_done[lane], c->stream), "event record"); c->last_probe_lane = lane; c->last_probe_side = true; }
                 std::swap(c->stream, c->probe_stream); swap_probe_buffers(c);
@@ -1619,7 +1635,7 @@ int rt_dispatch_rays(rt_ctx* c) {
         }
         else if (collect || (gather && c->sp_read_version[lane] != c->sp_version)) {
             if (c->last_probe_lane >= 0 && (c->last_probe_lane != lane || c->last_probe_side)) hip_ok(hipStreamWaitEvent(c->stream, c->probe_done[c->last_probe_lane], 0), "event wait");
-            if (rc == RT_OK && collect) { rc = run_pass(c, true); if (rc == RT_OK) c->sp_version++; } // raytracing.cpp:677-687
+            if (rc == RT_OK && collect) { rc = sample_pass(c); if (rc == RT_OK) c->sp_version++; } // raytracing.cpp:677-687
             if (rc == RT_OK) rc = refresh_read_points(c); // :723-728
             if (rc == RT_OK) { c->sp_read_version[lane] = c->sp_version; hip_ok(hipEventRecord(c->probe_done[lane], c->stream), "event record"); c->last_probe_lane = lane; c->last_probe_side = false; }
         }
@@ -1844,6 +1860,20 @@ int rt_pack_tiles(rt_ctx* c, uint32_t rank, uint32_t world, void* dev_packed) {
     if ((size_t) a.n_local_tiles * 1024 * 16 < bytes) // a rank with one tile less than the largest share: the tail is defined too
         RT_HIP(hipMemsetAsync((char*) dev_packed + (size_t) a.n_local_tiles * 1024 * 16, 0, bytes - (size_t) a.n_local_tiles * 1024 * 16, c->stream));
     return launch_pack_tiles(c->stream, a, dev_packed);
+}
+
+int rt_set_probe_split(rt_ctx* c, uint32_t rank, uint32_t world) {
+    if (!c || world == 0 || rank >= world) { set_error("rt_set_probe_split: bad arguments"); return RT_ERR_INVALID; }
+    { int qrc = quiesce(c); if (qrc) return qrc; }
+    c->probe_rank = rank; c->probe_world = world;
+    return RT_OK;
+}
+
+int rt_set_probe_exchange(rt_ctx* c, rt_probe_exchange_fn fn, void* user) {
+    if (!c) return RT_ERR_INVALID;
+    { int qrc = quiesce(c); if (qrc) return qrc; }
+    c->probe_exchange = fn; c->probe_exchange_user = user;
+    return RT_OK;
 }
 
 int rt_unpack_tiles(rt_ctx* c, uint32_t rank, uint32_t world, const void* dev_packed) {

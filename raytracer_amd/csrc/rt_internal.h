@@ -194,6 +194,7 @@ struct PassArgs {
     const float* sp_normal;      // 3 per point
     const u32* sp_slice;         // per point -> slice index
     u32 n_points;
+    u32 probe_lo, probe_hi;      // translucent_rgen dispatches trace the points [probe_lo, probe_hi) (all of them unless rt_set_probe_split)
     HgView hg;
     const float4* gather_delta;  // k_gather<3>: differences of consecutive scaled texels, fetched through L1 (launch_gather_delta); null: both texels from LDS
     const float* bssrdf_table;   // rgb interleaved

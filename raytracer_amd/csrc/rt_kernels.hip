@@ -299,7 +299,7 @@ RT_DEV void probe_finish_sample(const PassArgs& a, u32 p, f3 normal, f3& tsum) {
 __global__ __launch_bounds__(SEG) void k_probe_raygen(PassArgs a, u32 sample_index) {
     __shared__ u32 s_wave[SEG / 64];
     u32 p = blockIdx.x * SEG + threadIdx.x;
-    bool active = p < a.n_points;
+    bool active = p < a.n_points && p >= a.probe_lo && p < a.probe_hi; // (rt_set_probe_split: this rank's block of the points)
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
     if (active) {
         const TranslucentSlice& sl = a.shade.slices[a.sp_slice[p]];
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(SEG) void k_probe_raygen(PassArgs a, u32 sample_ind
 
 __global__ __launch_bounds__(BT) void k_probe_resolve(PassArgs a) {
     u32 p = blockIdx.x * BT + threadIdx.x;
-    if (p >= a.n_points) return;
+    if (p >= a.n_points || p < a.probe_lo || p >= a.probe_hi) return; // (the other ranks' blocks keep their payloads until the exchange)
     const TranslucentSlice& sl = a.shade.slices[a.sp_slice[p]];
     f3 normal = mk3(a.sp_normal[3 * p], a.sp_normal[3 * p + 1], a.sp_normal[3 * p + 2]);
     f3 tsum = mk3(a.ps.sum_x[p], a.ps.sum_y[p], a.ps.sum_z[p]);

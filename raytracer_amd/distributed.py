@@ -7,8 +7,12 @@ allows without changing any pixel's sample stream:
                       Other ranks' pixels stay zero in the accumulator; the exchange is a gather of the tiles each rank
                       owns (gather_tiles: 1 / world of the frame per rank, copied, not added), which reproduces it exactly
                       (so would a reduce(sum) of the zero-filled frames, at world times the bytes).
-                      The probe pass (translucent_rgen) is replicated on every rank: it is ~N_points*spp paths against
-                      W*H*spp camera paths, and replication keeps sample-point payloads bit-identical without an exchange.
+                      The probe pass (translucent_rgen) is replicated on every rank by default: it is ~N_points*spp paths
+                      against W*H*spp camera paths, and replication keeps sample-point payloads bit-identical without an
+                      exchange.  install_probe_exchange partitions it instead: rank r traces block r of the
+                      points and an all-gather of the payload blocks follows every pass, on the library's own sample-point
+                      stream, beside the frame's camera pass -- the same payloads bit for bit (each point is traced by
+                      exactly one rank, with the one-GPU arithmetic).
   sample split  (C5)  rank r renders frames r, r+world, ... of the frame_rng chain (main.cpp:443-454) into its own
                       accumulator; one reduce(sum) of the RGBA32F buffer at the end.  Equal to the sequential sum up to
                       float re-association -- for scenes WITHOUT translucent sample points: the sample-point payloads are
@@ -131,3 +135,65 @@ def reduce_accumulator(tensor, dist, dst=0, all_ranks=False):
     else:
         dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
     return tensor
+
+
+def exchange_point_blocks(points, n_points, block, rank, world, dist, stage_mine=None, stage_all=None):
+    """The exchange step of the partitioned sample-point pass on a flat float32 tensor `points` of n_points x 6 values
+    (RtSamplePoint: position, payload): rank r holds the fresh payloads of block r = points [r * block, min((r + 1) * block, n))
+    and receives every other block.  Equal-sized, zero-padded blocks through one all_gather (RCCL / gloo); runs on whatever
+    device and stream the tensors live on.  stage_*: reusable staging tensors (block * 6 and world * block * 6 values)."""
+    import torch
+    if stage_mine is None:
+        stage_mine = torch.zeros(block * 6, dtype=torch.float32, device=points.device)
+    if stage_all is None:
+        stage_all = torch.empty(world * block * 6, dtype=torch.float32, device=points.device)
+    lo = min(rank * block, n_points); hi = min(lo + block, n_points)
+    if hi > lo:
+        stage_mine[:(hi - lo) * 6].copy_(points[lo * 6:hi * 6])
+    if dist is not None:   # (a communicator of one rank still makes the call: bench.py --with-collectives rehearses it on a one-GPU box)
+        dist.all_gather_into_tensor(stage_all, stage_mine)
+    else:
+        stage_all[:block * 6].copy_(stage_mine)
+    points[:n_points * 6].copy_(stage_all[:n_points * 6])   # (blocks are contiguous: block r starts at r * block)
+    return points
+
+
+def install_probe_exchange(rt, dist, rank, world, device, via_host=False):
+    """Partitions the sample-point pass of `rt` over the ranks (rt_set_probe_split) and installs the all-gather of the payload
+    blocks behind every pass (rt_set_probe_exchange, include/rt_abi.h).  The library calls back with the HIP stream the pass was
+    enqueued on; the copies and the collective are enqueued on that stream (torch runs them on it as an external stream: RCCL's
+    own stream waits for it and it waits for RCCL), so nothing blocks the host and the exchange overlaps the frame's camera pass.
+    via_host: one-GPU rehearsal with gloo -- the stream is drained and the blocks go through host memory."""
+    import torch
+    stage = {}
+
+    def view(ptr, n):
+        class _Buf(object):
+            pass
+        b = _Buf()
+        b.__cuda_array_interface__ = {"shape": (n * 6,), "typestr": "<f4", "data": (ptr, False), "version": 3, "strides": None}
+        return torch.as_tensor(b, device=device)
+
+    def exchange(stream_ptr, points_ptr, n_points, block):
+        if n_points == 0:
+            return 0
+        ext = torch.cuda.ExternalStream(stream_ptr, device=device)
+        with torch.cuda.stream(ext):
+            pts = view(points_ptr, n_points)
+            if via_host:
+                ext.synchronize()
+                host_pts = pts.cpu()
+                exchange_point_blocks(host_pts, n_points, block, rank, world, dist)
+                pts.copy_(host_pts)
+                ext.synchronize()
+            else:
+                key = (n_points, block)
+                if key not in stage:   # (allocated once per point set: the tensors are reused by every frame, on this one stream)
+                    stage[key] = (torch.zeros(block * 6, dtype=torch.float32, device=device),
+                                  torch.empty(world * block * 6, dtype=torch.float32, device=device))
+                exchange_point_blocks(pts, n_points, block, rank, world, dist, *stage[key])
+        return 0
+
+    rt.set_probe_split(rank, world)
+    rt.set_probe_exchange(exchange)
+    return exchange

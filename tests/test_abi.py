@@ -27,9 +27,9 @@ def test_abi_version_and_struct_sizes():
     from raytracer_amd import _abi
     so = ctypes.CDLL(os.path.join(ROOT, "raytracer_amd/librt_mi355x.so"))
     so.rt_abi_version.restype = ctypes.c_int
-    assert so.rt_abi_version() == 2 == _abi.RT_ABI_VERSION
+    assert so.rt_abi_version() == 3 == _abi.RT_ABI_VERSION
     header = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
-    assert "#define RT_ABI_VERSION 2" in header
+    assert "#define RT_ABI_VERSION 3" in header
     assert ctypes.sizeof(_abi.RtGlobals) == 156                # prelude.h:110-139
     offs = {n: getattr(_abi.RtGlobals, n).offset for n, _ in _abi.RtGlobals._fields_}
     assert offs["camera_to_world"] == 16 and offs["camera_aspect"] == 80 and offs["translucent_accumulator_count"] == 88

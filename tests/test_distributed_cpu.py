@@ -93,6 +93,36 @@ def _worker(rank, world, port, mode, out_dir):
     dist.destroy_process_group()
 
 
+def _points_worker(rank, world, port, n_points, out_dir):
+    """distributed.exchange_point_blocks under gloo: rank r has the fresh payloads of block r of the points only"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    block = (n_points + world - 1) // world
+    rng = np.random.RandomState(5)
+    truth = rng.rand(n_points * 6).astype(np.float32)            # what one GPU would hold after the pass
+    stale = rng.rand(n_points * 6).astype(np.float32)            # the other blocks before the exchange
+    lo, hi = min(rank * block, n_points), min((rank + 1) * block, n_points)
+    mine = stale.copy(); mine[lo * 6:hi * 6] = truth[lo * 6:hi * 6]
+    pts = torch.from_numpy(mine)
+    for _ in range(2):                                           # twice: the staging tensors of a caller are reused
+        distributed.exchange_point_blocks(pts, n_points, block, rank, world, dist)
+    np.save(os.path.join(out_dir, "pts%d.npy" % rank), pts.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_points", [(2, 759), (3, 10), (3, 2), (2, 1)])
+def test_sample_point_blocks_are_all_gathered(tmp_path, world, n_points):
+    """the exchange of the partitioned sample-point pass (distributed.install_probe_exchange): equal,
+    zero-padded blocks -- the last one short, or empty when there are fewer points than ranks -- through one all_gather;
+    every rank ends with every block's fresh payloads"""
+    mp.spawn(_points_worker, args=(world, _free_port(), n_points, str(tmp_path)), nprocs=world, join=True)
+    truth = np.random.RandomState(5).rand(n_points * 6).astype(np.float32)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "pts%d.npy" % r))
+        assert np.array_equal(got.view(np.uint32), truth.view(np.uint32)), r
+
+
 def _run(mode, tmp_path, world=2):
     mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
     return np.load(os.path.join(str(tmp_path), "acc.npy"))

@@ -203,7 +203,7 @@ def test_status_codes_instead_of_abort():
         rt.close()
 
 
-@pytest.mark.parametrize("split", ["tile", "sample"])
+@pytest.mark.parametrize("split", ["tile", "sample", "tile+probe"])
 def test_two_ranks_of_the_product_reproduce_the_one_process_image(split, tmp_path):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), rehearsed on this box's
     one GPU (--rehearse: both ranks on GPU 0, gloo for the collective): rank 0's reduced accumulator against the image
@@ -214,11 +214,13 @@ def test_two_ranks_of_the_product_reproduce_the_one_process_image(split, tmp_pat
     from raytracer_amd import api, scenes, distributed
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "acc.npy")
+    probe = split == "tile+probe"   # the sample-point pass in two blocks, the payload blocks all-gathered behind every pass (--probe-split)
+    if probe: split = "tile"
     workload = "c4" if split == "tile" else "c2"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse",
            "--workload", workload, "--split", split, "--width", "256", "--height", "144", "--spp", "2", "--steps", "3",
-           "--warmup", "0", "--no-cpu", "--dump-accumulator", out]
+           "--warmup", "0", "--no-cpu", "--dump-accumulator", out] + (["--probe-split"] if probe else [])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -226,6 +228,7 @@ def test_two_ranks_of_the_product_reproduce_the_one_process_image(split, tmp_pat
     import json
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["scaling"] == ("strong" if split == "tile" else "weak") and rec["reduce_ms"] > 0
+    assert ("all-gather" in rec["config"]["parallelism"]) == probe
     got = np.load(out)
     scene = scenes.cornell_bunny(256, 144, spp=2, bounces=4) if split == "tile" else scenes.bunny(256, 144, spp=1, bounces=1)
     rt = api.Raytracer(0)
@@ -269,7 +272,7 @@ def test_the_scale_run_commands_at_baseline_size(workload, split, size, tmp_path
         assert rec["scaling"] == "weak" and rec["exchange"]["bytes_per_rank"] == frame_bytes
 
 
-@pytest.mark.parametrize("workload,split", [("c2", "sample"), ("c4", "tile")])
+@pytest.mark.parametrize("workload,split", [("c2", "sample"), ("c4", "tile"), ("c4", "tile+probe")])
 def test_the_rccl_calls_of_the_multi_gpu_path_as_a_one_rank_job(workload, split, tmp_path):
     """A one-GPU box cannot hold two RCCL ranks (one rank per device), so the backend calls of the N > 1 path -- process group
     on the "nccl" backend with a device id, reduce(sum) of the product's accumulator through its zero-copy view, gather of
@@ -279,7 +282,9 @@ def test_the_rccl_calls_of_the_multi_gpu_path_as_a_one_rank_job(workload, split,
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for tag, extra in (("plain", []), ("rccl", ["--with-collectives", "--split", split])):
+    probe = split == "tile+probe"   # and the all-gather of the sample points' payload blocks, on the library's sample-point stream
+    if probe: split = "tile"
+    for tag, extra in (("plain", []), ("rccl", ["--with-collectives", "--split", split] + (["--probe-split"] if probe else []))):
         dump = str(tmp_path / (tag + ".npy"))
         base = [os.path.join(root, "bench.py"), "--gpus", "1", "--workload", workload, "--width", "320", "--height", "180", "--steps", "3",
                 "--warmup", "1", "--no-cpu", "--no-alone", "--dump-accumulator", dump] + extra
