@@ -11,7 +11,7 @@ HIP_SRCS := $(CSRC)/rt_api.hip $(CSRC)/rt_kernels.hip $(CSRC)/rt_bvh.hip $(CSRC)
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
 HIP_HDRS := $(wildcard $(CSRC)/*.h) include/rt_abi.h
 
-all: raytracer_amd/librt_mi355x.so raytracer_amd/librt_host.so oracle/liboracle.so raytracer_amd/rt_render tools/valu_issue_bench
+all: raytracer_amd/librt_mi355x.so raytracer_amd/librt_host.so oracle/liboracle.so raytracer_amd/rt_render tools/valu_issue_bench tools/valu_class_bench tools/valu_exec_bench
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -28,6 +28,11 @@ raytracer_amd/rt_render: raytracer_amd/host/rt_render.cpp raytracer_amd/host/ray
 
 # microbenchmark behind bench.py's roofline peak (profiles/r02_valu_issue.txt)
 tools/valu_issue_bench: tools/valu_issue_bench.hip
+	$(HIPCC) --offload-arch=gfx950 -O2 -o $@ $<
+# which instruction kinds issue at the fast rate, and whether the exec mask matters (profiles/r03_valu_classes.txt, r03_valu_exec_mask.txt)
+tools/valu_class_bench: tools/valu_class_bench.hip
+	$(HIPCC) --offload-arch=gfx950 -O2 -o $@ $<
+tools/valu_exec_bench: tools/valu_exec_bench.hip
 	$(HIPCC) --offload-arch=gfx950 -O2 -o $@ $<
 
 oracle/liboracle.so: oracle/rt_oracle.cpp include/rt_abi.h

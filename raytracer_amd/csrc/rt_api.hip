@@ -587,7 +587,7 @@ int run_pass(rt_ctx* c, bool probe) {
     // measured 1e-7).
     rt_ctx::BatchGather* bg = nullptr;
     if (gather && !a.hg.enabled) { int brc = ensure_batch_gather(c, c->cur_lane, &bg); if (brc) return brc; }
-    const u32 rows_per_sample = gather ? (u32) std::min<int64_t>(c->g.translucent_emission_bounces, c->g.bounces_per_sample) + 1u : 0u;
+    const u32 rows_per_sample = (gather && c->g.translucent_emission_bounces >= 0) ? (u32) std::min<int64_t>(c->g.translucent_emission_bounces, c->g.bounces_per_sample) + 1u : 0u;
     // camera pass: no ray-generation kernel (bounce 0 derives rays from pixels), and unless a gather launch adds emission to the
     // paths' radiance between the bounces, no resolve kernel either: finished paths fold their sample into the pixel's sum in
     // k_shade (`fused`).  With the batched gather that holds for frames with translucent meshes too: the terms are added to the
