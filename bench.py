@@ -71,6 +71,40 @@ class _DevBuf(object):
                                          "strides": None}
 
 
+# kernels of the scene set-up (BVH builds, blue-noise points): in the PMC passes, not in a frame
+_SETUP_KERNELS = ("k_sah", "k_ploc", "k_morton", "k_sort_hist", "k_sort_scan", "k_sort_scatter", "k_pack_nodes", "k_flat_", "k_emit_single",
+                  "k_instance_boxes", "k_scene_box", "k_triangle_boxes", "k_trirecs", "k_invert_perm", "k_bn_")
+
+
+def pmc_frame_insts(ks):
+    """Vector instructions (wave64) of ONE pipelined frame from the per-kernel, per-launch means of a PMC entry: every render
+    kernel's mean x its launches, over the frames of the pass (= launches of k_frame_resolve, one per pipelined frame).  The
+    pass also holds bench.py's one counting frame: its k_traverse<true, ...> launches are left out, and so is the shade launch
+    that follows each of them (k_shade<.., 0>; unfused when the frame gathers, which its k_camera_resolve shows) and its share
+    of the once-per-frame kernels.  None when the entry has no pipelined frames."""
+    frames = ks.get("k_frame_resolve", {}).get("launches_sampled", 0)
+    if not frames:
+        return None
+    count_q = sum(v["launches_sampled"] for n, v in ks.items() if n.startswith("k_traverse<true, 1, false"))
+    count_p = sum(v["launches_sampled"] for n, v in ks.items() if n.startswith("k_traverse<true, 1, true"))
+    flag = "false" if "k_camera_resolve" in ks else "true"
+    total = 0.0
+    for name, v in ks.items():
+        if name.startswith(_SETUP_KERNELS) or name.startswith("k_traverse<true,"):
+            continue
+        if "<" not in name and any(m.startswith(name + "<") for m in ks):
+            continue    # the sum over a kernel's instantiations: those are listed by themselves
+        n = float(v["launches_sampled"])
+        if count_p:
+            if name == "k_shade<false, %s, 0>" % flag: n -= count_q
+            elif name == "k_shade<true, %s, 0>" % flag: n -= count_p
+            elif name == "k_camera_resolve": n = 0.0
+            elif name.startswith(("k_gather", "k_probe", "k_sort_payload")): n -= n / (frames + 1.0)
+        if n > 0 and v.get("SQ_INSTS_VALU") is not None:
+            total += v["SQ_INSTS_VALU"] * n
+    return total / frames
+
+
 def pmc_key(args):
     """entry of profiles/pmc_traffic.json for this command: the workload, with the size unless it is 1080p"""
     return args.workload if (args.width, args.height) == (1920, 1080) else "%s_%dx%d" % (args.workload, args.width, args.height)
@@ -461,20 +495,15 @@ def main():
                 if ns and k.get("SQ_INSTS_VALU") is not None and cyc_best:
                     e["valu_issue_frac"] = k["SQ_INSTS_VALU"] / ns / (SIMDS * CLOCK_GHZ / cyc_best)
                 other[name] = e
-        # the whole frame: vector instructions of ALL its kernels (the same PMC passes; c2 runs each of the five once per frame)
-        # against the issue slots of the frame's wall time, at the measured cost of the node step's blend.  With two frames
-        # in flight the kernels overlap, so this -- not the per-launch figure -- says how full the machine is.
+        # the whole frame: vector instructions of ALL its kernels (the same PMC passes) against the issue slots of the frame's wall
+        # time, at the measured cost of the node step's blend.  With two frames in flight the kernels overlap, so this -- not the
+        # per-launch figure -- says how full the machine is.  (Kernels other than the traversal have other blends -- the gather's is
+        # cheaper -- so for them the price is an upper bound.)
         frame_insts = frame_issue_frac = None
-        if pmc_all is not None and args.workload == "c2" and cyc_mix:
-            try:
-                ks = pmc_all
-                # the kernels every frame runs once: the instantiations (and k_frame_resolve) sampled about as often as the most sampled one
-                most = max(v["launches_sampled"] for v in ks.values())
-                per_frame = [k for k, v in ks.items() if ("<" in k or k == "k_frame_resolve") and v["launches_sampled"] >= 0.9 * most and v.get("SQ_INSTS_VALU")]
-                frame_insts = sum(ks[k]["SQ_INSTS_VALU"] for k in per_frame)
+        if pmc_all is not None and cyc_mix:
+            frame_insts = pmc_frame_insts(pmc_all)
+            if frame_insts:
                 frame_issue_frac = frame_insts * cyc_mix / (dt_max / args.steps * SIMDS * CLOCK_GHZ * 1e9)
-            except (KeyError, ValueError):
-                frame_insts = frame_issue_frac = None
         split_label = ("tile split x%d" if tile else "sample-set split x%d") % world
         out = {
             # BASELINE.json's metric; `value` is the whole job: per GPU at N = 1, the sum over the N GPUs otherwise

@@ -70,3 +70,25 @@ def test_committed_counter_passes_belong_to_the_committed_kernel_sources():
     entries = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
     for key in ("c2", "c3", "c4", "c5", "c5_3840x2160"):
         assert entries[key]["source_hash"] == want, "profiles/pmc_traffic.json[%r] is stale (%s, sources are %s)" % (key, entries[key]["source_hash"], want)
+
+
+def test_frame_instruction_count_from_a_counter_pass():
+    """bench.py's whole-frame issue figure: the vector instructions of one pipelined frame are every render kernel's mean
+    times its launches over the frames of the pass; set-up kernels and the one counting frame are left out"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    k = lambda n, insts: {"launches_sampled": n, "SQ_INSTS_VALU": insts}
+    ks = {"k_frame_resolve": k(10, 2.0), "k_shade": k(33, 1.0), "k_shade<true, true, 3>": k(10, 30.0), "k_shade<true, true, 0>": k(1, 9.0),
+          "k_shade<false, true, 0>": k(2, 7.0), "k_traverse": k(13, 1.0), "k_traverse<false, 8, false, false, false, 3>": k(10, 50.0),
+          "k_traverse<true, 1, true, false, false, 3>": k(1, 500.0), "k_traverse<true, 1, false, false, false, 3>": k(2, 600.0),
+          "k_sah_bin": k(40, 1000.0), "k_morton": k(3, 1000.0)}
+    assert bench.pmc_frame_insts(ks) == pytest.approx(82.0)          # 30 + 50 + 2: the counting frame's five launches and the build are out
+    # a frame that gathers: the counting frame is unfused (k_camera_resolve) and takes one share of the once-per-frame kernels
+    ks = {"k_frame_resolve": k(4, 1.0), "k_camera_resolve": k(1, 5.0), "k_gather": k(5, 1.0), "k_gather<1, 256>": k(5, 100.0), "k_probe_raygen": k(10, 3.0),
+          "k_shade<false, false, 0>": k(4 * 3 + 2, 10.0), "k_shade<true, false, 0>": k(1, 11.0), "k_shade<true, true, 0>": k(4, 20.0),
+          "k_traverse<false, 7, false, false, false, 2>": k(12, 40.0), "k_traverse<true, 1, false, false, false, 2>": k(2, 1.0),
+          "k_traverse<true, 1, true, false, false, 2>": k(1, 1.0), "k_bn_try": k(99, 1.0)}
+    assert bench.pmc_frame_insts(ks) == pytest.approx(1.0 + 100.0 + 2 * 3.0 + 3 * 10.0 + 20.0 + 3 * 40.0)
+    assert bench.pmc_frame_insts({"k_shade": k(3, 1.0)}) is None     # no pipelined frame in the pass
